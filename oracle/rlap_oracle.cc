@@ -1,0 +1,563 @@
+// rlap_oracle.cc -- CPU restatement of rLap's approximate-Cholesky / randomized
+// Schur-complement augmentor.
+//
+// *** TEST INFRASTRUCTURE ONLY. ***  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load this library.  The product path
+// (rlap_amd/) never links, imports or calls anything in oracle/.
+//
+// What it restates (all paths relative to /root/reference):
+//   rlap/csrc/py_api_binder.cc:54-69   op entry (edge_info (E,3) f64 -> (m,3) f64)
+//   rlap/csrc/factorizers.cc:46-65     setup: read -> symmetry check -> strategy
+//   rlap/csrc/factorizers.cc:18-40     computeLaplacian (symmetry check, D, L=D-A)
+//   rlap/csrc/reader.cc:42-61          COO -> CSC, w==0 rows dropped, dups summed
+//   rlap/csrc/preconditioner.cc:22-49  twin ("flip") indices
+//   rlap/csrc/preconditioner.cc:65-114 CSC -> per-column linked lists with twins
+//   rlap/csrc/preconditioner.cc:125-246 bucket priority queue (LIFO per bucket)
+//   rlap/csrc/preconditioner.cc:248-345 gather live entries, merge multi-edges, order
+//   rlap/csrc/preconditioner.cc:348-476 o_v="degree" elimination + output
+//   rlap/csrc/preconditioner.cc:713-825 o_v="random" elimination + output
+//   rlap/csrc/preconditioner.cc:835-957 o_v="coarsen" elimination + output
+//
+// Third-party arithmetic the reference leans on and that is NOT in /root/reference:
+//   Eigen 3.4.0 (setup.py:47, install.sh:5): setFromTriplets (sorted inner indices,
+//   duplicates summed), SparseMatrix::isApprox (||A-B||^2 <= 1e-24*min(||A||^2,||B||^2)).
+//   Restated below from Eigen's published semantics; the reference cannot be built
+//   here (Eigen headers absent, no network), see DESIGN.md.
+//   libstdc++ (present: this file is compiled against it): std::sort,
+//   std::mt19937_64 (default seed 5489), std::uniform_real_distribution<double>.
+//   They are used DIRECTLY, so tie order and rounding are the reference's.
+//
+// Parity pinning: SURVEY.md Appendix C known answers (RNG KAT, P4, K4, K6, star,
+// K5) -- tests/test_oracle_kat.py.  Outside those vectors parity is unpinned.
+//
+// Randomness the reference draws from std::random_device (vertex permutation for
+// o_v="random", neighbour shuffles for o_n="random"/coarsen) is injected instead:
+// `perm` (node_id vector, popped from the back, preconditioner.cc:588-613) and
+// `shuffle_seed` (keyed order, see keyed_order_dkey()).
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+namespace {
+
+// ---- keyed neighbour order used in place of std::shuffle(random_device) ------
+inline uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// phase 0 = elimination, 1 = output. The neighbours (in post-merge, ascending-id
+// order) are std::sort-ed ascending on this 52-bit key (exact in a double).
+inline double keyed_order_dkey(uint64_t seed, int64_t vertex, int phase, int64_t nbr) {
+    uint64_t base = mix64(seed ^ mix64(2ull * (uint64_t)vertex + (uint64_t)phase));
+    return (double)(mix64(base ^ mix64((uint64_t)nbr)) >> 12);
+}
+
+// 32-byte node, one heap allocation each, as types.h:7-51.
+struct Node {
+    double row;
+    double val;
+    Node* next;
+    Node* twin;
+};
+
+struct Csc {
+    int64_t n = 0;
+    std::vector<int64_t> colptr;
+    std::vector<int32_t> row;
+    std::vector<double> val;
+};
+
+// reader.cc:42-61 (+ Eigen setFromTriplets): drop w==0, column-major, sorted
+// rows, duplicates summed in input order.
+int build_csc(const double* ei, int64_t E, int64_t n, Csc& A) {
+    A.n = n;
+    A.colptr.assign(n + 1, 0);
+    std::vector<int64_t> keep;
+    keep.reserve(E);
+    for (int64_t p = 0; p < E; ++p) {
+        if (ei[3 * p + 2] != 0) {
+            int64_t r = (int64_t)ei[3 * p], c = (int64_t)ei[3 * p + 1];
+            if (r < 0 || r >= n || c < 0 || c >= n) return 2;
+            keep.push_back(p);
+            A.colptr[c + 1]++;
+        }
+    }
+    for (int64_t c = 0; c < n; ++c) A.colptr[c + 1] += A.colptr[c];
+    int64_t nz = A.colptr[n];
+    std::vector<int32_t> row(nz);
+    std::vector<double> val(nz);
+    {
+        std::vector<int64_t> cur(A.colptr.begin(), A.colptr.end() - 1);
+        for (int64_t p : keep) {
+            int64_t c = (int64_t)ei[3 * p + 1];
+            row[cur[c]] = (int32_t)ei[3 * p];
+            val[cur[c]] = ei[3 * p + 2];
+            cur[c]++;
+        }
+    }
+    // per column: stable sort by row, sum duplicates
+    std::vector<int64_t> newptr(n + 1, 0);
+    std::vector<int64_t> idx;
+    A.row.clear();
+    A.val.clear();
+    A.row.reserve(nz);
+    A.val.reserve(nz);
+    for (int64_t c = 0; c < n; ++c) {
+        int64_t s = A.colptr[c], e = A.colptr[c + 1];
+        idx.resize(e - s);
+        for (int64_t k = 0; k < e - s; ++k) idx[k] = s + k;
+        std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return row[a] < row[b]; });
+        int64_t k = 0;
+        while (k < e - s) {
+            int32_t r = row[idx[k]];
+            double v = val[idx[k]];
+            ++k;
+            while (k < e - s && row[idx[k]] == r) { v += val[idx[k]]; ++k; }
+            A.row.push_back(r);
+            A.val.push_back(v);
+        }
+        newptr[c + 1] = (int64_t)A.row.size();
+    }
+    A.colptr.swap(newptr);
+    return 0;
+}
+
+// factorizers.cc:18-40. isApprox(A^T) with Eigen's default precision 1e-12:
+// ||A - A^T||_F^2 <= 1e-24 * ||A||_F^2. The reference then also forms D and
+// L = D - A (unused afterwards) -- done here too when `faithful` so the CPU
+// baseline carries the same overhead.
+int check_symmetric(const Csc& A, bool faithful) {
+    int64_t n = A.n;
+    double norm2 = 0, diff2 = 0;
+    for (int64_t c = 0; c < n; ++c) {
+        for (int64_t p = A.colptr[c]; p < A.colptr[c + 1]; ++p) {
+            double v = A.val[p];
+            norm2 += v * v;
+            int64_t r = A.row[p];
+            // find (c, r) in column r
+            auto b = A.row.begin() + A.colptr[r], e = A.row.begin() + A.colptr[r + 1];
+            auto it = std::lower_bound(b, e, (int32_t)c);
+            double w = (it != e && *it == (int32_t)c) ? A.val[it - A.row.begin()] : 0.0;
+            double d = v - w;
+            // entries present only in A^T are counted from their own side when
+            // visited as (r,c) of the transposed pair; a missing twin adds v^2 once
+            // here and, since the twin does not exist, never again: add it twice.
+            diff2 += (it != e && *it == (int32_t)c) ? d * d : 2 * d * d;
+        }
+    }
+    if (!(diff2 <= 1e-24 * norm2)) return 1;
+    if (faithful) {
+        std::vector<double> deg(n, 0.0);
+        for (int64_t c = 0; c < n; ++c)
+            for (int64_t p = A.colptr[c]; p < A.colptr[c + 1]; ++p) deg[A.row[p]] += A.val[p];
+        // L = D - A as CSC (merge of a diagonal and A)
+        std::vector<int64_t> lp(n + 1, 0);
+        std::vector<int32_t> lr;
+        std::vector<double> lv;
+        lr.reserve(A.row.size() + n);
+        lv.reserve(A.row.size() + n);
+        for (int64_t c = 0; c < n; ++c) {
+            bool placed = false;
+            for (int64_t p = A.colptr[c]; p < A.colptr[c + 1]; ++p) {
+                if (!placed && A.row[p] >= c) {
+                    if (A.row[p] == c) { lr.push_back((int32_t)c); lv.push_back(deg[c] - A.val[p]); placed = true; continue; }
+                    lr.push_back((int32_t)c); lv.push_back(deg[c]); placed = true;
+                }
+                lr.push_back(A.row[p]); lv.push_back(-A.val[p]);
+            }
+            if (!placed) { lr.push_back((int32_t)c); lv.push_back(deg[c]); }
+            lp[c + 1] = (int64_t)lr.size();
+        }
+        volatile double sink = lv.empty() ? 0.0 : lv.back();
+        (void)sink;
+    }
+    return 0;
+}
+
+// preconditioner.cc:22-49: position of the transposed entry. With a symmetric
+// pattern, walking columns in order visits column r's entries in order.
+std::vector<int64_t> twin_index(const Csc& A) {
+    std::vector<int64_t> cur(A.colptr.begin(), A.colptr.end() - 1);
+    std::vector<int64_t> tw(A.row.size());
+    for (int64_t c = 0; c < A.n; ++c)
+        for (int64_t p = A.colptr[c]; p < A.colptr[c + 1]; ++p) tw[p] = cur[A.row[p]]++;
+    return tw;
+}
+
+struct Lists {
+    int64_t n;
+    std::vector<double> degs;
+    std::vector<Node*> head;   // PriorityMatrix::cols
+    std::vector<Node*> all;    // PriorityMatrix::lles
+    std::vector<Node*> dummy;  // empty-column placeholders (leaked by the reference)
+};
+
+// preconditioner.cc:65-114
+Lists* build_lists(const Csc& A) {
+    Lists* L = new Lists();
+    L->n = A.n;
+    std::vector<int64_t> tw = twin_index(A);
+    L->all.reserve(A.row.size());
+    for (int64_t c = 0; c < A.n; ++c) {
+        int64_t s = A.colptr[c], e = A.colptr[c + 1];
+        L->degs.push_back((double)(e - s));
+        if (e == s) {
+            Node* d = new Node{0, 0, nullptr, nullptr};
+            d->next = d; d->twin = d;
+            L->head.push_back(d);
+            L->dummy.push_back(d);
+            continue;
+        }
+        Node* first = new Node{(double)A.row[s], A.val[s], nullptr, nullptr};
+        first->next = first; first->twin = first;
+        L->all.push_back(first);
+        Node* nxt = first;
+        for (int64_t p = s + 1; p < e; ++p) {
+            Node* nd = new Node{(double)A.row[p], A.val[p], nxt, nullptr};
+            nd->twin = nd;
+            L->all.push_back(nd);
+            nxt = nd;
+        }
+        L->head.push_back(nxt);
+    }
+    for (size_t p = 0; p < L->all.size(); ++p) L->all[p]->twin = L->all[tw[p]];
+    return L;
+}
+
+void free_lists(Lists* L) {
+    for (Node* p : L->all) delete p;
+    for (Node* p : L->dummy) delete p;
+    delete L;
+}
+
+// preconditioner.cc:125-246; types.h:80-121. Elements are allocated one by one.
+struct PqElem { double prev, next, key; };
+struct DegPq {
+    std::vector<PqElem*> el;
+    std::vector<double> lists;
+    double minlist = 0, nitems = 0, n = 0;
+    int64_t moves = 0;
+};
+
+DegPq* pq_build(const std::vector<double>& degs) {
+    DegPq* q = new DegPq();
+    int64_t n = (int64_t)degs.size();
+    q->el.assign(n, nullptr);
+    q->lists.assign(2 * n + 1, -1.0);
+    for (int64_t i = 0; i < n; ++i) {
+        double key = degs[i];
+        double hd = q->lists[(int64_t)key];
+        PqElem* e = new PqElem{-1, hd >= 0 ? hd : -1, key};
+        q->el[i] = e;
+        if (hd >= 0) q->el[(int64_t)hd]->prev = (double)i;
+        q->lists[(int64_t)key] = (double)i;
+    }
+    q->nitems = (double)n;
+    q->n = (double)n;
+    return q;
+}
+
+int64_t pq_pop(DegPq* q) {
+    while (q->lists[(int64_t)q->minlist] == -1) q->minlist += 1;
+    int64_t i = (int64_t)q->lists[(int64_t)q->minlist];
+    double nx = q->el[i]->next;
+    q->lists[(int64_t)q->minlist] = nx;
+    delete q->el[i];
+    q->el[i] = nullptr;
+    if (nx > -1) q->el[(int64_t)nx]->prev = -1;
+    q->nitems -= 1;
+    return i;
+}
+
+void pq_move(DegPq* q, int64_t i, double newkey, int64_t oldlist, int64_t newlist) {
+    q->moves++;
+    PqElem* e = q->el[i];
+    double pv = e->prev, nx = e->next;
+    if (nx > -1) q->el[(int64_t)nx]->prev = pv;
+    if (pv > -1) q->el[(int64_t)pv]->next = nx; else q->lists[oldlist] = nx;
+    double hd = q->lists[newlist];
+    if (hd > -1) q->el[(int64_t)hd]->prev = (double)i;
+    q->lists[newlist] = (double)i;
+    e->prev = -1; e->next = hd; e->key = newkey;
+}
+
+inline int64_t pq_list_of(double key, double n) { return key <= n ? (int64_t)key : (int64_t)(n + (int)(key / n)); }
+
+void pq_dec(DegPq* q, int64_t i) {
+    double k = q->el[i]->key;
+    if (k == 1) return;
+    int64_t ol = pq_list_of(k, q->n), nl = pq_list_of(k - 1, q->n);
+    if (ol != nl) {
+        pq_move(q, i, k - 1, ol, nl);
+        if ((double)nl < q->minlist) q->minlist = (double)nl;
+    } else q->el[i]->key -= 1;
+}
+
+void pq_inc(DegPq* q, int64_t i) {
+    double k = q->el[i]->key;
+    int64_t ol = pq_list_of(k, q->n), nl = pq_list_of(k + 1, q->n);
+    if (ol != nl) pq_move(q, i, k + 1, ol, nl); else q->el[i]->key += 1;
+}
+
+void pq_free(DegPq* q) {
+    for (PqElem* e : q->el) delete e;
+    delete q;
+}
+
+// preconditioner.cc:248-271
+int64_t gather_live(Lists* L, int64_t i, std::vector<Node*>& cs) {
+    Node* p = L->head[i];
+    int64_t len = 0;
+    auto put = [&](Node* x) {
+        ++len;
+        if ((size_t)len > cs.size()) cs.push_back(x); else cs[len - 1] = x;
+    };
+    while (p->next != p) {
+        if (p->val > 0) put(p);
+        p = p->next;
+    }
+    if (p->val > 0) put(p);
+    return len;
+}
+
+struct Ctx {
+    int o_n;          // 0 asc, 1 desc, 2 random(keyed)
+    int sort_mode;    // 0 std::sort (libstdc++), 1 std::stable_sort
+    uint64_t shuffle_seed;
+};
+
+template <class Cmp>
+inline void do_sort(const Ctx& cx, std::vector<Node*>& cs, int64_t cnt, Cmp cmp) {
+    if (cx.sort_mode == 0) std::sort(cs.begin(), cs.begin() + cnt, cmp);
+    else std::stable_sort(cs.begin(), cs.begin() + cnt, cmp);
+}
+
+inline void order_by_on(const Ctx& cx, std::vector<Node*>& cs, int64_t cnt, int64_t vertex, int phase) {
+    if (cx.o_n == 0) do_sort(cx, cs, cnt, [](Node* a, Node* b) { return a->val < b->val; });
+    else if (cx.o_n == 1) do_sort(cx, cs, cnt, [](Node* a, Node* b) { return a->val > b->val; });
+    else {
+        // reference: std::shuffle seeded from std::random_device (:303-307) -- injected here
+        uint64_t seed = cx.shuffle_seed;
+        do_sort(cx, cs, cnt, [&](Node* a, Node* b) {
+            return keyed_order_dkey(seed, vertex, phase, (int64_t)a->row) < keyed_order_dkey(seed, vertex, phase, (int64_t)b->row);
+        });
+    }
+}
+
+// preconditioner.cc:273-310 (pq==nullptr: :641-676); output variant :312-345
+int64_t compress(const Ctx& cx, std::vector<Node*>& cs, int64_t len, DegPq* pq, bool output_phase, int64_t vertex) {
+    do_sort(cx, cs, len, [](Node* a, Node* b) { return a->row < b->row; });
+    int64_t ptr = -1;
+    double cur = -1;
+    for (int64_t i = 0; i < len; ++i) {
+        if (cs[i]->row != cur) {
+            cur = cs[i]->row;
+            ++ptr;
+            cs[ptr] = cs[i];
+        } else {
+            cs[ptr]->val += cs[i]->val;
+            if (!output_phase) {
+                cs[i]->twin->val = 0;
+                if (pq) pq_dec(pq, (int64_t)cur);
+            }
+        }
+    }
+    order_by_on(cx, cs, ptr + 1, vertex, output_phase ? 1 : 0);
+    return ptr + 1;
+}
+
+struct Out {
+    std::vector<double> rows;  // (m,3) row-major
+    void emit(double r, double c, double v) { rows.push_back(r); rows.push_back(c); rows.push_back(v); }
+};
+
+inline double draw(std::mt19937_64& g, std::uniform_real_distribution<double>& d) { return d(g); }
+
+// :377-418 / :740-776 : the sampled star -> tree rewrite, shared by degree/random
+inline void rewire(Lists* L, Node* ll, double j, double k, double w) {
+    Node* rv = ll->twin;
+    rv->row = k; rv->val = w; rv->twin = ll;
+    Node* kh = L->head[(int64_t)k];
+    L->head[(int64_t)k] = ll;
+    ll->next = kh; ll->twin = rv; ll->val = w; ll->row = j;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct rlap_oracle_stats {
+    int64_t n_eliminated;
+    int64_t n_draws;
+    int64_t n_pq_moves;
+    int64_t nnz;
+    double t_setup;   // read + symmetry + lists + pq
+    double t_elim;
+    double t_output;  // output loop + teardown
+    double t_total;
+};
+
+// o_v: 0 random, 1 degree, 2 coarsen.  o_n: 0 asc, 1 desc, 2 random.
+// perm: required for o_v==0 (node_id vector; vertices are popped from the BACK).
+// order_out (nullable, n entries): vertices in pop order (eliminated then output).
+// Returns 0 ok, 1 not symmetric, 2 index out of range, 3 bad argument.
+int rlap_oracle_approx_chol(const double* edge_info, int64_t E, int64_t n, int64_t t, int o_v, int o_n,
+                            const int64_t* perm, uint64_t shuffle_seed, int sort_mode, int faithful,
+                            double** out, int64_t* out_rows, int64_t* order_out, rlap_oracle_stats* st) {
+    using clk = std::chrono::steady_clock;
+    auto T0 = clk::now();
+    if (o_v < 0 || o_v > 2 || o_n < 0 || o_n > 2) return 3;
+    if (o_v == 0 && !perm && n > 0) return 3;
+    Csc A;
+    int rc = build_csc(edge_info, E, n, A);
+    if (rc) return rc;
+    rc = check_symmetric(A, faithful != 0);
+    if (rc) return rc;
+    Ctx cx{o_v == 2 ? 2 : o_n, sort_mode, shuffle_seed};  // coarsen forces "random" (:830-831)
+    Lists* L = build_lists(A);
+    DegPq* pq = (o_v != 0) ? pq_build(L->degs) : nullptr;
+    std::vector<int64_t> rq;
+    int64_t rq_items = n;
+    if (o_v == 0) rq.assign(perm, perm + n);
+    auto T1 = clk::now();
+
+    std::vector<Node*> cs;
+    std::mt19937_64 gen;  // default seed, :356
+    std::uniform_real_distribution<double> ud(0, 1);
+    Out o;
+    int64_t ndraw = 0, nelim = 0, npop = 0;
+    double dn = (double)n;
+    double it = 1;
+    std::vector<double> cum, vals;
+    while (it <= (double)t && it < dn) {
+        int64_t i;
+        if (o_v == 0) { i = rq[rq_items - 1]; rq_items--; } else { i = pq_pop(pq); it += 1; }
+        if (order_out) order_out[npop] = i;
+        ++npop; ++nelim;
+        int64_t len = gather_live(L, i, cs);
+        len = compress(cx, cs, len, pq, false, i);
+        if (o_v == 2) {
+            // coarsen :853-912
+            if (len < 1) continue;
+            double csum = 0;
+            cum.clear(); vals.clear();
+            for (int64_t a = 0; a < len; ++a) { vals.push_back(cs[a]->val); csum += cs[a]->val; cum.push_back(csum); }
+            double u = draw(gen, ud); ++ndraw;
+            double r = u * csum;
+            int64_t koff = len - 1;
+            for (int64_t a = 0; a < len; ++a) if (cum[a] > r) { koff = a; break; }
+            double k = cs[koff]->row, wk = vals[koff];
+            Node* kp = cs[koff];
+            kp->val = 0; kp->twin->val = 0;
+            pq_dec(pq, (int64_t)k);
+            for (int64_t jo = 0; jo < len; ++jo) {
+                if (jo == koff) continue;
+                Node* ll = cs[jo];
+                double w = vals[jo], j = ll->row;
+                pq_inc(pq, (int64_t)k);
+                double nw = (wk * w) / (wk + w);
+                rewire(L, ll, j, k, nw);
+            }
+            continue;
+        }
+        double csum = 0;
+        cum.clear(); vals.clear();
+        for (int64_t a = 0; a < len; ++a) { vals.push_back(cs[a]->val); csum += cs[a]->val; cum.push_back(csum); }
+        double wdeg = csum, colScale = 1;
+        for (int64_t jo = 0; jo < len - 1; ++jo) {
+            Node* ll = cs[jo];
+            double w = vals[jo] * colScale;
+            double j = ll->row;
+            double f = w / wdeg;
+            double u = draw(gen, ud); ++ndraw;
+            double r = u * (csum - cum[jo]) + cum[jo];
+            int64_t koff = len - 1;
+            for (int64_t a = 0; a < len; ++a) if (cum[a] > r) { koff = a; break; }
+            double k = cs[koff]->row;
+            if (pq) pq_inc(pq, (int64_t)k);
+            double nw = f * (1 - f) * wdeg;
+            rewire(L, ll, j, k, nw);
+            colScale = colScale * (1 - f);
+            wdeg = wdeg * (1 - f) * (1 - f);
+        }
+        if (len > 0) {
+            Node* ll = cs[len - 1];
+            Node* rv = ll->twin;
+            if (pq && it < dn) pq_dec(pq, (int64_t)ll->row);
+            ll->val = 0; rv->val = 0;
+        }
+        if (o_v == 0) it += 1;
+    }
+    auto T2 = clk::now();
+
+    // output loops :435-457 / :789-810 / :916-934
+    while ((o_v == 0 ? (double)rq_items : pq->nitems) > 0) {
+        int64_t i;
+        if (o_v == 0) { i = rq[rq_items - 1]; rq_items--; } else i = pq_pop(pq);
+        if (order_out) order_out[npop] = i;
+        ++npop;
+        int64_t len = gather_live(L, i, cs);
+        len = compress(cx, cs, len, pq, true, i);
+        for (int64_t a = 0; a < len; ++a) o.emit(cs[a]->row, (double)i, cs[a]->val);
+    }
+    int64_t m = (int64_t)(o.rows.size() / 3);
+    double* res = (double*)std::malloc(sizeof(double) * (size_t)(m > 0 ? 3 * m : 1));
+    if (m) std::memcpy(res, o.rows.data(), sizeof(double) * 3 * (size_t)m);
+    int64_t moves = pq ? pq->moves : 0;
+    if (pq) pq_free(pq);
+    free_lists(L);
+    auto T3 = clk::now();
+    *out = res;
+    *out_rows = m;
+    if (st) {
+        auto sec = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        st->n_eliminated = nelim; st->n_draws = ndraw; st->n_pq_moves = moves; st->nnz = (int64_t)A.row.size();
+        st->t_setup = sec(T0, T1); st->t_elim = sec(T1, T2); st->t_output = sec(T2, T3); st->t_total = sec(T0, T3);
+    }
+    return 0;
+}
+
+void rlap_oracle_free(double* p) { std::free(p); }
+
+// First `count` uniforms of the sampling stream:
+// default-seeded std::mt19937_64 through uniform_real_distribution<double>(0,1).
+void rlap_oracle_uniforms(int64_t count, double* u, uint64_t* raw) {
+    std::mt19937_64 g, g2;
+    std::uniform_real_distribution<double> d(0, 1);
+    for (int64_t i = 0; i < count; ++i) {
+        if (raw) raw[i] = g2();
+        u[i] = d(g);
+    }
+}
+
+// std::sort permutation of `cnt` doubles under `less` (desc=0) or `greater`
+// (desc=1): perm_out[i] = original index of the element that ends at position i.
+// Used by tests to pin the HIP introsort emulation against libstdc++ itself.
+void rlap_oracle_stdsort_perm(const double* keys, int64_t cnt, int desc, int64_t* perm_out) {
+    struct P { double k; int64_t i; };
+    std::vector<P> v((size_t)cnt);
+    for (int64_t i = 0; i < cnt; ++i) v[i] = P{keys[i], i};
+    if (desc) std::sort(v.begin(), v.end(), [](const P& a, const P& b) { return a.k > b.k; });
+    else std::sort(v.begin(), v.end(), [](const P& a, const P& b) { return a.k < b.k; });
+    for (int64_t i = 0; i < cnt; ++i) perm_out[i] = v[i].i;
+}
+
+// std::partial_sort(first,last,last) (= introsort's depth-limit fallback) permutation.
+void rlap_oracle_heapsort_perm(const double* keys, int64_t cnt, int desc, int64_t* perm_out) {
+    struct P { double k; int64_t i; };
+    std::vector<P> v((size_t)cnt);
+    for (int64_t i = 0; i < cnt; ++i) v[i] = P{keys[i], i};
+    if (desc) std::partial_sort(v.begin(), v.end(), v.end(), [](const P& a, const P& b) { return a.k > b.k; });
+    else std::partial_sort(v.begin(), v.end(), v.end(), [](const P& a, const P& b) { return a.k < b.k; });
+    for (int64_t i = 0; i < cnt; ++i) perm_out[i] = v[i].i;
+}
+
+}  // extern "C"

@@ -1,0 +1,515 @@
+// rlap_core.h -- data-structure logic shared by the HIP kernels (device) and the
+// host-side mirror used by the CPU unit tests (tests/csrc/host_mirror.cc).
+// Everything here is plain sequential C++ on caller-provided arrays; the
+// wave-parallel parts live in the .hip files.
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   rlap/csrc/preconditioner.cc:125-246  bucket PQ (LIFO per bucket)  -> lazy bucket stacks
+//   rlap/csrc/preconditioner.cc:273-345  std::sort calls               -> std_sort_emul()
+//   rlap/csrc/preconditioner.cc:65-114,404-414 linked column lists     -> CSR segment + chunks
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RLAP_HD __host__ __device__ __forceinline__
+#define RLAP_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define RLAP_HD inline
+#define RLAP_HD_NOINLINE inline
+#endif
+
+namespace rlap {
+
+enum { OV_RANDOM = 0, OV_DEGREE = 1, OV_COARSEN = 2 };
+enum { ON_ASC = 0, ON_DESC = 1, ON_RANDOM = 2 };
+
+// status codes returned through the C ABI (include/rlap_hip.h)
+enum {
+    ST_OK = 0,
+    ST_NOT_SYMMETRIC = 1,
+    ST_INDEX_RANGE = 2,
+    ST_BAD_ARG = 3,
+    ST_POOL_OVERFLOW = 4,
+    ST_LOG_OVERFLOW = 5,
+    ST_RNG_OVERFLOW = 6,
+    ST_OUT_OVERFLOW = 7,
+    ST_HIP_ERROR = 8,
+    ST_TOO_LARGE = 9,
+    ST_INTERNAL = 10,
+};
+
+// ---------------------------------------------------------------------------
+// Keyed neighbour order: replaces std::shuffle(std::random_device) of
+// preconditioner.cc:303-307,340-342 by an injected, reproducible order
+// (ascending (key, nbr)).  Same definition in oracle/rlap_oracle.cc.
+// ---------------------------------------------------------------------------
+RLAP_HD uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+RLAP_HD uint64_t keyed_order_base(uint64_t seed, int64_t vertex, int phase) {
+    return mix64(seed ^ mix64(2ull * (uint64_t)vertex + (uint64_t)phase));
+}
+RLAP_HD uint64_t keyed_order_key(uint64_t base, int64_t nbr) { return mix64(base ^ mix64((uint64_t)nbr)); }
+
+// ---------------------------------------------------------------------------
+// Appended-entry chunks.  Column v = CSR segment [colptr[v], colptr[v+1]) plus
+// `app_cnt[v]` appended entries kept in geometrically growing chunks:
+// chunk c holds appended indices [CHUNK0*(2^c-1), CHUNK0*(2^(c+1)-1)).
+// A chunk occupies (1 + capacity) slots: slot `base` is a header whose e_nbr
+// field links to the previous (older) chunk's base, entries follow.
+// Reference traversal order (head = newest push, then CSC order reversed,
+// preconditioner.cc:84-97,409-411) = appended indices descending, then the CSR
+// segment descending.
+// ---------------------------------------------------------------------------
+constexpr int CHUNK0 = 8;
+RLAP_HD int chunk_of(int a) {  // chunk index of appended index a
+    unsigned q = (unsigned)a / CHUNK0 + 1u;
+    int c = 0;
+    while (q > 1u) { q >>= 1; ++c; }
+    return c;
+}
+RLAP_HD int chunk_start(int c) { return CHUNK0 * ((1 << c) - 1); }
+RLAP_HD int chunk_cap(int c) { return CHUNK0 << c; }
+
+// ---------------------------------------------------------------------------
+// Bucket index of a PQ key: preconditioner.cc:222-223,238-239
+// ---------------------------------------------------------------------------
+RLAP_HD int pq_list_of(int key, int n) { return key <= n ? key : n + key / n; }
+
+// One PQ op on a target, tracked as (key, mv): `mv` = number of the last op
+// that changed the target's bucket (a move re-inserts it at the bucket head,
+// preconditioner.cc:192-214), -1 if none so far.  delta=+1: DegreePQInc
+// (:235-246); delta=-1: DegreePQDec (:216-233, a no-op at key 1).
+RLAP_HD void pq_op(int& key, int& mv, int n, int delta, int opnum) {
+    if (delta < 0 && key == 1) return;
+    int ol = pq_list_of(key, n), nl = pq_list_of(key + delta, n);
+    key += delta;
+    if (ol != nl) mv = opnum;
+}
+
+// ---------------------------------------------------------------------------
+// Sort records and an exact re-statement of libstdc++ 11 std::sort
+// (/usr/include/c++/11/bits/stl_algo.h:1810-1960, stl_heap.h:128-430):
+// introsort loop (median-of-3 to first, unguarded Hoare partition, threshold
+// 16, depth limit 2*floor(lg n), heap-sort fallback) + final insertion sort.
+// The reference sorts POINTERS with a strict-weak comparator on one field, so
+// the resulting permutation under ties is a function of this algorithm only.
+// ---------------------------------------------------------------------------
+struct SRec {
+    double key;
+    int32_t idx;
+    int32_t aux;
+};
+
+template <bool GREATER>
+RLAP_HD bool srec_less(const SRec& a, const SRec& b) {
+    return GREATER ? (a.key > b.key) : (a.key < b.key);
+}
+
+template <bool GREATER, class P>
+RLAP_HD void ss_adjust_heap(P a, int first, int hole, int len, SRec value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (srec_less<GREATER>(a[first + child], a[first + child - 1])) child--;
+        a[first + hole] = a[first + child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[first + hole] = a[first + child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && srec_less<GREATER>(a[first + parent], value)) {
+        a[first + hole] = a[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[first + hole] = value;
+}
+
+template <bool GREATER, class P>
+RLAP_HD void ss_heap_sort(P a, int first, int last) {  // __partial_sort(first,last,last)
+    int len = last - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            SRec v = a[first + parent];
+            ss_adjust_heap<GREATER>(a, first, parent, len, v);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int l = last;
+    while (l - first > 1) {
+        --l;
+        SRec v = a[l];
+        a[l] = a[first];
+        ss_adjust_heap<GREATER>(a, first, 0, l - first, v);
+    }
+}
+
+// introsort phase only (everything before __final_insertion_sort)
+template <bool GREATER, class P>
+RLAP_HD void ss_introsort_loop(P a, int n) {
+    if (n <= 16) return;
+    int depth0 = 0;
+    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+    depth0 *= 2;
+    // explicit stack replaces the recursion on the right part
+    int stk_first[72], stk_last[72], stk_depth[72];
+    int sp = 0;
+    stk_first[0] = 0; stk_last[0] = n; stk_depth[0] = depth0; sp = 1;
+    while (sp > 0) {
+        --sp;
+        int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
+        while (last - first > 16) {
+            if (depth == 0) { ss_heap_sort<GREATER>(a, first, last); break; }
+            --depth;
+            // __move_median_to_first(first, first+1, mid, last-1)
+            int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+            int pick;
+            if (srec_less<GREATER>(a[ia], a[ib])) {
+                if (srec_less<GREATER>(a[ib], a[ic])) pick = ib;
+                else if (srec_less<GREATER>(a[ia], a[ic])) pick = ic;
+                else pick = ia;
+            } else if (srec_less<GREATER>(a[ia], a[ic])) pick = ia;
+            else if (srec_less<GREATER>(a[ib], a[ic])) pick = ic;
+            else pick = ib;
+            { SRec t = a[first]; a[first] = a[pick]; a[pick] = t; }
+            // __unguarded_partition(first+1, last, pivot=first)
+            SRec pv = a[first];
+            int f = first + 1, l = last;
+            while (true) {
+                while (srec_less<GREATER>(a[f], pv)) ++f;
+                --l;
+                while (srec_less<GREATER>(pv, a[l])) --l;
+                if (!(f < l)) break;
+                SRec t = a[f]; a[f] = a[l]; a[l] = t;
+                ++f;
+            }
+            int cut = f;
+            // recurse on [cut,last), continue with [first,cut)
+            stk_first[sp] = cut; stk_last[sp] = last; stk_depth[sp] = depth; ++sp;
+            last = cut;
+        }
+    }
+}
+
+// __final_insertion_sort == stable insertion sort of the whole range (the
+// unguarded part never runs past the sentinel left by the partitions).
+template <bool GREATER, class P>
+RLAP_HD void ss_insertion_sort(P a, int n) {
+    for (int i = 1; i < n; ++i) {
+        SRec v = a[i];
+        int j = i - 1;
+        while (j >= 0 && srec_less<GREATER>(v, a[j])) { a[j + 1] = a[j]; --j; }
+        a[j + 1] = v;
+    }
+}
+
+template <bool GREATER, class P>
+RLAP_HD void std_sort_emul(P a, int n) {
+    if (n < 2) return;
+    ss_introsort_loop<GREATER>(a, n);
+    ss_insertion_sort<GREATER>(a, n);
+}
+
+// Key of the injected "random" neighbour order: a 52-bit hash, exact in a double.
+// The order itself is std::sort (emulated) ascending on this key, applied to the
+// neighbours in post-merge (ascending id) order.
+RLAP_HD double keyed_order_dkey(uint64_t base, int64_t nbr) { return (double)(keyed_order_key(base, nbr) >> 12); }
+
+// ---------------------------------------------------------------------------
+// Device-resident state (SoA, int32 indices, f64 weights).
+// ---------------------------------------------------------------------------
+struct GraphDesc {      // one per graph of a batch
+    int32_t vbase;      // global id of local vertex 0
+    int32_t n;          // vertices
+    int64_t t;          // num_remove
+    int32_t bucket_base;  // into bhead/ocur/oend, 2n+1 buckets
+    int32_t log_base;   // into log_v/log_prev
+    int32_t log_cap;
+    int32_t scr_base;   // big-column scratch, in entries
+    int32_t scr_cap;
+    // running state / results
+    int32_t minlist;
+    int32_t log_cnt;
+    int32_t n_elim;
+    int32_t status;
+    int64_t n_draws;
+    int64_t out_rows;   // rows this graph emits (filled by the output pass)
+};
+
+struct ColBuf {         // working storage for one column (LDS or global scratch)
+    SRec* rec;
+    int32_t* a_slot; int32_t* a_nbr; int32_t* a_twin; double* a_val;
+    int32_t* b_slot; int32_t* b_nbr; int32_t* b_twin; double* b_val;
+    double* cum; double* newv;
+    int32_t* ksel; int32_t* t_key; int32_t* t_mv; int32_t* t_of;  // t_of[j] = b-index of final position j
+};
+
+struct Arrays {
+    const int32_t* colptr;   // [N+1]
+    int32_t* e_nbr; double* e_val; int32_t* e_twin;  // [slot_cap]; slots [0,nnz) = CSR, rest = chunk pool
+    int32_t slot_cap;
+    int32_t* pool_top;       // next free slot (device counter)
+    int32_t* app_cnt; int32_t* app_chunk;            // [N]
+    int32_t* key; int32_t* pqpos;                    // [N]; pqpos -1 = original place, >=0 log entry, -2 popped
+    int32_t* bhead; int32_t* ocur; int32_t* oend;    // [sum(2n+1)]
+    const int32_t* orig_order;                       // [N] global ids by (graph, deg asc, id desc)
+    int32_t* log_v; int32_t* log_prev;
+    const double* rng; int64_t rng_len;
+    const int64_t* perm;     // [N] local ids (o_v random), graph g at [vbase, vbase+n)
+    int32_t o_v; int32_t o_n;
+    uint64_t shuffle_seed;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+RLAP_HD int32_t pool_take(int32_t* top, int32_t cnt) { return atomicAdd(top, cnt); }
+#else
+RLAP_HD int32_t pool_take(int32_t* top, int32_t cnt) { int32_t r = *top; *top = r + cnt; return r; }
+#endif
+
+// Append one entry to column k; returns its slot or -1 on pool overflow.
+RLAP_HD int32_t col_append(const Arrays& A, int32_t k) {
+    int32_t a = A.app_cnt[k];
+    int c = chunk_of(a);
+    int cs = chunk_start(c);
+    if (a == cs) {
+        int32_t need = 1 + chunk_cap(c);
+        int32_t base = pool_take(A.pool_top, need);
+        if (base < 0 || base > A.slot_cap - need) return -1;
+        A.e_nbr[base] = A.app_chunk[k];
+        A.app_chunk[k] = base;
+    }
+    A.app_cnt[k] = a + 1;
+    return A.app_chunk[k] + 1 + (a - cs);
+}
+
+// preconditioner.cc:248-271 on the array layout. Returns the live count.
+RLAP_HD int32_t serial_gather(const Arrays& A, int32_t v, const ColBuf& B, int32_t cap) {
+    int32_t len = 0;
+    int32_t a = A.app_cnt[v];
+    if (a > 0) {
+        int32_t base = A.app_chunk[v];
+        int c = chunk_of(a - 1);
+        int32_t idx = a - 1;
+        while (idx >= 0) {
+            int32_t cs = chunk_start(c);
+            for (int32_t t = idx; t >= cs; --t) {
+                int32_t s = base + 1 + (t - cs);
+                double val = A.e_val[s];
+                if (val > 0) {
+                    if (len < cap) { B.a_slot[len] = s; B.a_nbr[len] = A.e_nbr[s]; B.a_val[len] = val; B.a_twin[len] = A.e_twin[s]; }
+                    ++len;
+                }
+            }
+            idx = cs - 1;
+            base = A.e_nbr[base];
+            --c;
+        }
+    }
+    for (int32_t s = A.colptr[v + 1] - 1; s >= A.colptr[v]; --s) {
+        double val = A.e_val[s];
+        if (val > 0) {
+            if (len < cap) { B.a_slot[len] = s; B.a_nbr[len] = A.e_nbr[s]; B.a_val[len] = val; B.a_twin[len] = A.e_twin[s]; }
+            ++len;
+        }
+    }
+    return len;
+}
+
+// Lazy bucket stacks == the reference's doubly linked bucket lists
+// (preconditioner.cc:125-190): newest move first, then never-moved vertices
+// in descending id. Stale entries (vertex moved again / popped) are skipped.
+RLAP_HD int32_t pq_pop(const Arrays& A, GraphDesc& G) {
+    while (true) {
+        int32_t b = G.bucket_base + G.minlist;
+        int32_t e = A.bhead[b];
+        while (e >= 0) {
+            int32_t v = A.log_v[G.log_base + e];
+            int32_t pe = A.log_prev[G.log_base + e];
+            if (A.pqpos[v] == e) { A.bhead[b] = pe; A.pqpos[v] = -2; return v; }
+            e = pe;
+        }
+        A.bhead[b] = -1;
+        int32_t oc = A.ocur[b], oe = A.oend[b];
+        while (oc < oe) {
+            int32_t v = A.orig_order[oc++];
+            if (A.pqpos[v] == -1) { A.ocur[b] = oc; A.pqpos[v] = -2; return v; }
+        }
+        A.ocur[b] = oc;
+        G.minlist += 1;
+        if (G.minlist > 2 * G.n) return -1;  // empty queue (callers never pop then)
+    }
+}
+
+// Commit the per-target PQ results of one elimination: B.t_key/t_mv indexed by
+// merged index x in [0,m), vertex ids in B.b_nbr.  Moves are pushed in op order.
+RLAP_HD int pq_commit_serial(const Arrays& A, GraphDesc& G, const ColBuf& B, int32_t m) {
+    int32_t cnt = 0;
+    for (int32_t x = 0; x < m; ++x) {
+        A.key[B.b_nbr[x]] = B.t_key[x];
+        if (B.t_mv[x] >= 0) { B.rec[cnt].key = (double)B.t_mv[x]; B.rec[cnt].idx = x; B.rec[cnt].aux = 0; ++cnt; }
+    }
+    std_sort_emul<false>(B.rec, cnt);  // distinct keys
+    for (int32_t i = 0; i < cnt; ++i) {
+        int32_t x = B.rec[i].idx;
+        int32_t v = B.b_nbr[x];
+        int32_t lst = pq_list_of(B.t_key[x], G.n);
+        if (G.log_cnt >= G.log_cap) return ST_LOG_OVERFLOW;
+        int32_t e = G.log_cnt++;
+        A.log_v[G.log_base + e] = v;
+        A.log_prev[G.log_base + e] = A.bhead[G.bucket_base + lst];
+        A.bhead[G.bucket_base + lst] = e;
+        A.pqpos[v] = e;
+        if (lst < G.minlist) G.minlist = lst;
+    }
+    return ST_OK;
+}
+
+// Sort gathered entries by neighbour id exactly as std::sort would
+// (preconditioner.cc:275-276), then merge equal neighbours (:278-293).
+// elim=true additionally kills the twins of merged duplicates and records the
+// PQ Decs.  Leaves survivors in B.b_* (ascending id); returns their count.
+RLAP_HD int32_t serial_sort_merge(const Arrays& A, const GraphDesc& G, const ColBuf& B, int32_t len0, bool elim, bool use_pq) {
+    for (int32_t i = 0; i < len0; ++i) { B.rec[i].key = (double)B.a_nbr[i]; B.rec[i].idx = i; B.rec[i].aux = 0; }
+    std_sort_emul<false>(B.rec, len0);
+    int32_t m = 0;
+    for (int32_t i = 0; i < len0; ++i) {
+        int32_t s = B.rec[i].idx;
+        if (m == 0 || B.a_nbr[s] != B.b_nbr[m - 1]) {
+            B.b_slot[m] = B.a_slot[s]; B.b_nbr[m] = B.a_nbr[s]; B.b_val[m] = B.a_val[s]; B.b_twin[m] = B.a_twin[s];
+            if (elim && use_pq) { B.t_key[m] = A.key[B.a_nbr[s]]; B.t_mv[m] = -1; }
+            ++m;
+        } else {
+            B.b_val[m - 1] += B.a_val[s];
+            if (elim) {
+                A.e_val[B.a_twin[s]] = 0;
+                if (use_pq) pq_op(B.t_key[m - 1], B.t_mv[m - 1], G.n, -1, i);
+            }
+        }
+    }
+    return m;
+}
+
+// Order the m merged neighbours by o_n (:295-307) into B.a_*; B.t_of[j] = merged index.
+RLAP_HD void serial_order(const Arrays& A, const ColBuf& B, int32_t m, int32_t vertex, int phase) {
+    if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
+        uint64_t base = keyed_order_base(A.shuffle_seed, vertex, phase);
+        for (int32_t i = 0; i < m; ++i) { B.rec[i].key = keyed_order_dkey(base, B.b_nbr[i]); B.rec[i].idx = i; B.rec[i].aux = 0; }
+        std_sort_emul<false>(B.rec, m);
+    } else {
+        for (int32_t i = 0; i < m; ++i) { B.rec[i].key = B.b_val[i]; B.rec[i].idx = i; B.rec[i].aux = 0; }
+        if (A.o_n == ON_ASC) std_sort_emul<false>(B.rec, m); else std_sort_emul<true>(B.rec, m);
+    }
+    for (int32_t j = 0; j < m; ++j) {
+        int32_t x = B.rec[j].idx;
+        B.t_of[j] = x;
+        B.a_slot[j] = B.b_slot[x]; B.a_nbr[j] = B.b_nbr[x]; B.a_val[j] = B.b_val[x]; B.a_twin[j] = B.b_twin[x];
+    }
+}
+
+RLAP_HD int32_t upper_index(const double* cum, int32_t m, double r) {  // first a with cum[a] > r, else m-1 (:387-393)
+    int32_t lo = 0, hi = m;
+    while (lo < hi) {
+        int32_t mid = (lo + hi) >> 1;
+        if (cum[mid] > r) hi = mid; else lo = mid + 1;
+    }
+    return lo < m ? lo : m - 1;
+}
+
+RLAP_HD int serial_rewire(const Arrays& A, int32_t s_r, int32_t nbr_j, int32_t k, double w) {
+    int32_t s_n = col_append(A, k);
+    if (s_n < 0) return ST_POOL_OVERFLOW;
+    A.e_nbr[s_r] = k; A.e_val[s_r] = w; A.e_twin[s_r] = s_n;
+    A.e_nbr[s_n] = nbr_j; A.e_val[s_n] = w; A.e_twin[s_n] = s_r;
+    return ST_OK;
+}
+
+// One elimination, sequential form.  `e1` = 1-based elimination number (the
+// reference's `it` before its increment).  preconditioner.cc:358-433 (degree),
+// :723-787 (random), :846-914 (coarsen).
+RLAP_HD int serial_eliminate(const Arrays& A, GraphDesc& G, const ColBuf& B, int32_t cap, int32_t v, int64_t e1) {
+    const bool use_pq = A.o_v != OV_RANDOM;
+    int32_t len0 = serial_gather(A, v, B, cap);
+    if (len0 > cap) return ST_INTERNAL;
+    int32_t m = serial_sort_merge(A, G, B, len0, true, use_pq);
+    serial_order(A, B, m, v, 0);
+    if (A.o_v == OV_COARSEN) {
+        if (m >= 1) {
+            double csum = 0;
+            for (int32_t j = 0; j < m; ++j) { csum += B.a_val[j]; B.cum[j] = csum; }
+            if (G.n_draws >= A.rng_len) return ST_RNG_OVERFLOW;
+            double u = A.rng[G.n_draws]; G.n_draws += 1;
+            double r = u * csum;
+            int32_t koff = upper_index(B.cum, m, r);
+            int32_t k = B.a_nbr[koff];
+            double wk = B.a_val[koff];
+            A.e_val[B.a_twin[koff]] = 0;
+            int32_t xk = B.t_of[koff];
+            pq_op(B.t_key[xk], B.t_mv[xk], G.n, -1, len0);
+            for (int32_t j = 0; j < m; ++j) {
+                if (j == koff) continue;
+                pq_op(B.t_key[xk], B.t_mv[xk], G.n, +1, len0 + 1 + j);
+                double w = B.a_val[j];
+                double nw = (wk * w) / (wk + w);
+                int rc = serial_rewire(A, B.a_twin[j], B.a_nbr[j], k, nw);
+                if (rc) return rc;
+            }
+        }
+    } else {
+        double csum = 0;
+        for (int32_t j = 0; j < m; ++j) { csum += B.a_val[j]; B.cum[j] = csum; }
+        if (m > 1 && G.n_draws + (m - 1) > A.rng_len) return ST_RNG_OVERFLOW;
+        double wdeg = csum, colScale = 1;
+        for (int32_t j = 0; j < m - 1; ++j) {
+            double w = B.a_val[j] * colScale;
+            double f = w / wdeg;
+            double u = A.rng[G.n_draws + j];
+            double r = u * (csum - B.cum[j]) + B.cum[j];
+            int32_t koff = upper_index(B.cum, m, r);
+            B.ksel[j] = koff;
+            double omf = 1 - f;
+            B.newv[j] = f * omf * wdeg;
+            colScale = colScale * omf;
+            wdeg = wdeg * omf * omf;
+        }
+        if (m > 1) G.n_draws += m - 1;
+        for (int32_t j = 0; j < m - 1; ++j) {
+            int32_t koff = B.ksel[j];
+            if (use_pq) { int32_t xk = B.t_of[koff]; pq_op(B.t_key[xk], B.t_mv[xk], G.n, +1, len0 + j); }
+            int rc = serial_rewire(A, B.a_twin[j], B.a_nbr[j], B.a_nbr[koff], B.newv[j]);
+            if (rc) return rc;
+        }
+        if (m > 0) {
+            if (use_pq && e1 + 1 < (int64_t)G.n) { int32_t xl = B.t_of[m - 1]; pq_op(B.t_key[xl], B.t_mv[xl], G.n, -1, len0 + m); }
+            A.e_val[B.a_twin[m - 1]] = 0;
+        }
+    }
+    if (use_pq) return pq_commit_serial(A, G, B, m);
+    return ST_OK;
+}
+
+// Output of one surviving vertex (:440-453 + :312-345): rows (nbr, v, w) in o_n
+// order written to out[3*row0 ...]; returns the row count. count_only skips writes.
+RLAP_HD int32_t serial_output(const Arrays& A, const GraphDesc& G, const ColBuf& B, int32_t cap, int32_t v, double* out, int64_t row0, bool count_only) {
+    int32_t len0 = serial_gather(A, v, B, cap);
+    if (len0 > cap) return -1;
+    int32_t m = serial_sort_merge(A, G, B, len0, false, false);
+    if (count_only) return m;
+    serial_order(A, B, m, v, 1);
+    for (int32_t j = 0; j < m; ++j) {
+        double* o = out + 3 * (row0 + j);
+        o[0] = (double)B.a_nbr[j]; o[1] = (double)v; o[2] = B.a_val[j];
+    }
+    return m;
+}
+
+}  // namespace rlap
