@@ -1,0 +1,117 @@
+/* rlap_hip.h -- C ABI of librlap_hip.so, the MI355X (gfx950) implementation of
+ * rLap's approximate-Cholesky / randomized Schur-complement augmentor.
+ *
+ * This is the drop-in boundary for ONE path of kvignesh1420/rlap:
+ *   torch op  extension_cpp::approximate_cholesky(Tensor edge_info, int num_nodes,
+ *             int num_remove, str o_v, str o_n) -> Tensor
+ *             (reference: rlap/csrc/py_api_binder.cc:54-69,80-88)
+ *   torch op  extension_cpp::identity(Tensor a) -> Tensor
+ *             (reference: rlap/csrc/py_api_binder.cc:71-76)
+ * which are what rlap/ops.py:52-58 and :61-63 call.  Plain pointers and sizes
+ * only; every array pointer is DEVICE memory unless its name starts with h_.
+ * All work is enqueued on the handle's HIP stream; the call returns after the
+ * (few) scalars it reports have been copied back.
+ */
+#ifndef RLAP_HIP_H
+#define RLAP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rlap_handle_s* rlap_handle;
+
+/* o_v: reference strings "random" / "degree" / "coarsen" (rlap/ops.py:49) */
+enum { RLAP_OV_RANDOM = 0, RLAP_OV_DEGREE = 1, RLAP_OV_COARSEN = 2 };
+/* o_n: reference strings "asc" / "desc" / "random" (rlap/ops.py:50) */
+enum { RLAP_ON_ASC = 0, RLAP_ON_DESC = 1, RLAP_ON_RANDOM = 2 };
+
+/* status codes */
+enum {
+    RLAP_OK = 0,
+    RLAP_E_NOT_SYMMETRIC = 1, /* reference: prints + exit(0), factorizers.cc:19-22 */
+    RLAP_E_INDEX_RANGE = 2,
+    RLAP_E_BAD_ARG = 3,
+    RLAP_E_POOL_OVERFLOW = 4, /* internal growth limits; the call retries with a larger */
+    RLAP_E_LOG_OVERFLOW = 5,  /* workspace by itself, these only surface if that fails  */
+    RLAP_E_RNG_OVERFLOW = 6,
+    RLAP_E_OUT_OVERFLOW = 7,  /* out_cap_rows too small; *needed rows reported */
+    RLAP_E_HIP = 8,
+    RLAP_E_TOO_LARGE = 9,     /* nnz + growth pool exceeds int32 slot ids */
+    RLAP_E_INTERNAL = 10
+};
+
+typedef struct {
+    int64_t nnz;          /* directed entries after zero-drop + duplicate sum */
+    int64_t n_eliminated; /* sum over graphs of min(t, n-1) (preconditioner.cc:358) */
+    int64_t n_draws;      /* uniforms consumed (max over graphs)              */
+    int64_t out_rows;     /* rows of sc_edge_info                             */
+    int64_t live_entries; /* L: live directed entries read by the output pass */
+    float ms_setup;       /* COO->CSR, symmetry, twins, PQ init (HIP events)  */
+    float ms_elim;        /* elimination kernel                               */
+    float ms_output;      /* sc_order + sc_merge + sc_compact                 */
+    float ms_sc_merge;    /* output pass A alone                              */
+    float ms_sc_compact;  /* output pass B alone (ballot/prefix compaction)   */
+    float ms_total;
+} rlap_stats;
+
+/* Lifetime.  A handle binds to the HIP device current at creation and owns a
+ * grow-only device workspace and the cached MT19937-64 uniform table. */
+int rlap_create(rlap_handle* out);
+int rlap_destroy(rlap_handle h);
+int rlap_set_stream(rlap_handle h, void* hip_stream); /* hipStream_t; NULL = default */
+int rlap_set_timing(rlap_handle h, int enable);       /* fill rlap_stats.ms_* with HIP events */
+const char* rlap_status_string(int status);
+
+/* identity: (rows, cols) f64 row-major -> column-major staging -> row-major.
+ * Replaces extension_cpp::identity (py_api_binder.cc:71-76, tensorToEigen :10-31,
+ * eigenToTensor :33-51).  d_tmp needs rows*cols doubles. */
+int rlap_identity(rlap_handle h, const double* d_in, double* d_tmp, double* d_out, int64_t rows, int64_t cols);
+
+/* Split the reference's packed edge_info (E,3) f64 row-major [row, col, w]
+ * (rlap/ops.py:47) into the COO arrays the calls below take. */
+int rlap_unpack_edge_info(rlap_handle h, const double* d_edge_info, int64_t E, int64_t* d_row, int64_t* d_col, double* d_w);
+
+/* The op.  Replaces ApproximateCholesky::setup + getSchurComplement
+ * (factorizers.cc:46-73) for one graph:
+ *   d_row/d_col/d_w : COO, E directed entries (d_w NULL = all ones; w==0 rows are
+ *                     dropped, duplicates summed: reader.cc:42-61)
+ *   n, t            : num_nodes, num_remove
+ *   d_perm          : o_v=random only: the node_id vector (a permutation of
+ *                     0..n-1) popped from the BACK (preconditioner.cc:588-613);
+ *                     the reference draws it from std::random_device
+ *   shuffle_seed    : o_n=random / o_v=coarsen only: seed of the keyed neighbour
+ *                     order that stands in for std::shuffle(random_device)
+ *   d_out           : (out_cap_rows,3) f64 row-major [row, col, w]
+ *   h_out_rows      : rows written (or needed, with RLAP_E_OUT_OVERFLOW)      */
+int rlap_approx_chol(rlap_handle h, const int64_t* d_row, const int64_t* d_col, const double* d_w, int64_t E,
+                     int64_t n, int64_t t, int o_v, int o_n, const int64_t* d_perm, uint64_t shuffle_seed,
+                     double* d_out, int64_t out_cap_rows, int64_t* h_out_rows, rlap_stats* h_stats);
+
+/* Batched graphs (a disjoint union): graph g owns the node ids
+ * [h_node_ptr[g], h_node_ptr[g+1]); no edge may cross graphs.  Each graph is
+ * eliminated independently with its own num_remove and its own restart of the
+ * sampling stream -- what G separate reference calls would do.  d_perm holds,
+ * for graph g, a permutation of LOCAL ids 0..n_g-1 at [node_ptr[g], node_ptr[g+1]).
+ * Rows come out grouped by graph, with global node ids; h_out_row_ptr[G+1]. */
+int rlap_approx_chol_batched(rlap_handle h, const int64_t* d_row, const int64_t* d_col, const double* d_w, int64_t E,
+                             int64_t G, const int64_t* h_node_ptr, const int64_t* h_num_remove, int o_v, int o_n,
+                             const int64_t* d_perm, uint64_t shuffle_seed, double* d_out, int64_t out_cap_rows,
+                             int64_t* h_out_row_ptr, rlap_stats* h_stats);
+
+/* First `count` uniforms of the sampling stream (default-seeded std::mt19937_64
+ * through uniform_real_distribution<double>(0,1), preconditioner.cc:356-357)
+ * as generated on the device; for known-answer tests. */
+int rlap_rng_uniforms(rlap_handle h, int64_t count, double* d_out);
+
+/* Host-side synthetic input (bench/tests): Barabasi-Albert graph as a symmetric,
+ * coalesced COO sorted by (col,row).  Returns the directed entry count; call with
+ * NULL arrays to size them (upper bound 2*m*(n-m)). */
+int64_t rlap_util_ba_graph(int64_t n, int64_t m, uint64_t seed, int64_t* h_row, int64_t* h_col);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+// rlap_kernels.h -- kernel declarations shared by rlap_kernels.hip and rlap_api.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rlap_core.h"
+
+namespace rlap {
+
+enum { FLAG_RANGE = 0, FLAG_CROSS = 1, FLAG_COUNT = 4 };
+constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
+constexpr int SCAP = 512;  // output pass: same
+
+// Global scratch for columns too long for LDS (sequential fallback).
+struct ElimScratch {
+    SRec* rec;
+    int32_t* i32;   // 10 arrays of `cap` ints, interleaved per array
+    double* f64;    // 4 arrays of `cap` doubles
+    int64_t cap;    // total entries over all graphs
+    __host__ __device__ ColBuf colbuf(int64_t base) const {
+        ColBuf B;
+        B.rec = rec + base;
+        B.a_slot = i32 + base; B.a_nbr = i32 + cap + base; B.a_twin = i32 + 2 * cap + base;
+        B.b_slot = i32 + 3 * cap + base; B.b_nbr = i32 + 4 * cap + base; B.b_twin = i32 + 5 * cap + base;
+        B.ksel = i32 + 6 * cap + base; B.t_key = i32 + 7 * cap + base; B.t_mv = i32 + 8 * cap + base; B.t_of = i32 + 9 * cap + base;
+        B.a_val = f64 + base; B.b_val = f64 + cap + base; B.cum = f64 + 2 * cap + base; B.newv = f64 + 3 * cap + base;
+        return B;
+    }
+};
+
+struct ScScratch {
+    SRec* rec;
+    int32_t* i32;   // 7 arrays (a_slot,a_nbr,a_twin,b_slot,b_nbr,b_twin,t_of)
+    double* f64;    // 2 arrays (a_val,b_val)
+    int64_t cap;
+    unsigned long long* top;
+    __host__ __device__ ColBuf colbuf(int64_t base) const {
+        ColBuf B;
+        B.rec = rec + base;
+        B.a_slot = i32 + base; B.a_nbr = i32 + cap + base; B.a_twin = i32 + 2 * cap + base;
+        B.b_slot = i32 + 3 * cap + base; B.b_nbr = i32 + 4 * cap + base; B.b_twin = i32 + 5 * cap + base;
+        B.t_of = i32 + 6 * cap + base;
+        B.ksel = nullptr; B.t_key = nullptr; B.t_mv = nullptr;
+        B.a_val = f64 + base; B.b_val = f64 + cap + base; B.cum = nullptr; B.newv = nullptr;
+        return B;
+    }
+};
+
+__global__ void k_mt19937_64_table(double* out, int64_t count);
+__global__ void k_transpose_copy(const double* in, double* out, int64_t rows, int64_t cols, int to_colmajor);
+__global__ void k_unpack_edge_info(const double* ei, int64_t E, int64_t* row, int64_t* col, double* w);
+__global__ void k_vertex_graph(const int64_t* node_ptr, int G, int32_t* vgraph, int64_t N);
+__global__ void k_edge_keys(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t N, const int32_t* vgraph,
+                            uint64_t* keys, uint32_t* idx, int32_t* flags);
+__global__ void k_heads(const uint64_t* keys, int64_t E, int32_t* head);
+__global__ void k_fill_csr(const uint64_t* keys, const uint32_t* idx, const int32_t* head, const int32_t* pos, const double* w,
+                           int64_t E, int32_t* e_nbr, double* e_val, int32_t* slot_col, int32_t* deg);
+__global__ void k_twin_sym(const int32_t* colptr, const int32_t* e_nbr, const double* e_val, const int32_t* slot_col, int32_t nnz,
+                           int32_t* e_twin, double* acc);
+__global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, int32_t* key, int32_t* pqpos, int32_t* app_cnt,
+                          int32_t* app_chunk, uint64_t* skey, uint32_t* sval);
+__global__ void k_bucket_bounds(const uint32_t* order, const int32_t* key, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
+                                int32_t* ocur, int32_t* oend, int32_t* origpos);
+__global__ void k_eliminate(Arrays A, GraphDesc* gd, ElimScratch S);
+__global__ void k_sc_keys(const int32_t* key, const int32_t* pqpos, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,
+                          int32_t N, uint64_t* skey, uint32_t* sval);
+__global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,
+                                uint32_t* order);
+__global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const int32_t* app_cnt, int32_t S, int32_t* ext);
+__global__ void k_sc_merge(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
+                           const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, ScScratch SS,
+                           unsigned long long* live_total);
+__global__ void k_sc_compact(const uint32_t* order, const int32_t* cnt, const int64_t* row_off, const int64_t* tmp_off,
+                             const int32_t* tmp_nbr, const double* tmp_val, int32_t S, double* out);
+__global__ void k_graph_rows(const int64_t* surv_base, const int64_t* row_off, int32_t G, int64_t* out_ptr);
+
+}  // namespace rlap

@@ -1,0 +1,29 @@
+"""Synthetic inputs for benches and tests (host side; not part of the hot path).
+
+`barabasi_albert` follows the networkx / PyG construction (repeated-endpoint list),
+seeded, and returns the symmetric coalesced edge_index the reference's tests feed
+the op (tests/test_rlap.py:25-31: barabasi_albert_graph + to_undirected).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def barabasi_albert(num_nodes: int, num_edges: int, seed: int = 0) -> torch.Tensor:
+    lib = _lib.load()
+    cap = lib.rlap_util_ba_graph(num_nodes, num_edges, seed, None, None)
+    row = np.empty(max(cap, 1), dtype=np.int64)
+    col = np.empty(max(cap, 1), dtype=np.int64)
+    E = lib.rlap_util_ba_graph(num_nodes, num_edges, seed, row.ctypes.data, col.ctypes.data)
+    return torch.from_numpy(np.stack([row[:E], col[:E]]))
+
+
+def batch_disjoint(edge_indices, num_nodes):
+    """Concatenate graphs into one disjoint union; returns (edge_index, node_ptr)."""
+    ptr = [0]
+    parts = []
+    for ei, n in zip(edge_indices, num_nodes):
+        parts.append(ei + ptr[-1])
+        ptr.append(ptr[-1] + int(n))
+    return torch.cat(parts, dim=1), torch.tensor(ptr, dtype=torch.int64)

@@ -1,0 +1,254 @@
+"""Python host side of the augmentor: the reference's operator interface
+(rlap/ops.py:7-63) on top of the C ABI of librlap_hip.so.
+
+Same positional signature, same asserts, same return contract ((m,3) float64
+[row, col, w], CPU tensor by default).  Differences, all deliberate:
+  * inputs stay on the GPU (no `.cpu()` round trip, ops.py:47); CPU inputs are
+    copied to the current HIP device -- there is no CPU compute path;
+  * node ids are not squeezed through float32 (ops.py:47 promotes to f32 first,
+    exact only below 2^24);
+  * asymmetric input raises ValueError instead of exit(0) (factorizers.cc:19-22);
+  * the randomness the reference takes from std::random_device is drawn from
+    torch's RNG (or the keyword-only `perm` / `seed`), so runs are reproducible.
+"""
+from typing import Optional, Sequence, Tuple, Union
+import ctypes
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+O_V = {"random": 0, "degree": 1, "coarsen": 2}
+O_N = {"asc": 0, "desc": 1, "random": 2}
+
+_handles = {}
+last_stats = None  # rlap_stats of the most recent call (dict), for benches/tests
+
+
+def _device_for(t: Optional[Tensor]) -> torch.device:
+    if t is not None and t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("rlap_amd needs a HIP device (MI355X); no GPU is visible and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _handle(device: torch.device):
+    lib = _lib.load()
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    h = _handles.get(idx)
+    if h is None:
+        with torch.cuda.device(idx):
+            hp = ctypes.c_void_p()
+            rc = lib.rlap_create(ctypes.byref(hp))
+            if rc != 0:
+                raise RuntimeError(f"rlap_create failed: {_lib.status_string(rc)}")
+        h = hp
+        _handles[idx] = h
+    lib.rlap_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+    return lib, h
+
+
+def set_timing(enable: bool, device=None):
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    lib, h = _handle(dev)
+    lib.rlap_set_timing(h, 1 if enable else 0)
+
+
+def _raise(rc: int):
+    msg = _lib.status_string(rc)
+    if rc in (1, 2, 3):
+        raise ValueError(f"rlap: {msg}")
+    raise RuntimeError(f"rlap: {msg} (status {rc})")
+
+
+def _prep_edges(edge_index: Tensor, edge_weights: Optional[Tensor], dev: torch.device):
+    assert edge_index.shape[0] == 2
+    E = edge_index.shape[1]
+    ei = edge_index.to(device=dev, dtype=torch.int64)
+    row = ei[0].contiguous()
+    col = ei[1].contiguous()
+    w = None
+    if edge_weights is not None:
+        w = edge_weights.to(device=dev, dtype=torch.float64).reshape(-1).contiguous()  # (1,E) or (E,)
+        assert w.numel() == E, "edge_weights must have one entry per edge"
+    return row, col, w, E
+
+
+def _seed_from(seed: Optional[int]) -> int:
+    if seed is None:
+        return int(torch.randint(0, 2**62, (1,)).item())
+    return int(seed) & (2**64 - 1)
+
+
+def approximate_cholesky(
+    edge_index: Tensor,
+    edge_weights: Optional[Tensor],
+    num_nodes: int,
+    num_remove: int,
+    o_v: str,
+    o_n: str,
+    *,
+    perm: Optional[Tensor] = None,
+    seed: Optional[int] = None,
+    return_device: Optional[Union[str, torch.device]] = "cpu",
+) -> Tensor:
+    """Randomized Schur complement of the graph Laplacian (reference: rlap/ops.py:7-58).
+
+    Keyword-only extras: `perm` (o_v="random": the elimination order vector, popped
+    from the back, preconditioner.cc:588-613), `seed` (draws `perm` / the neighbour
+    shuffles reproducibly), `return_device` ("cpu" as the reference, None/"same" to
+    keep the result on the GPU).
+    """
+    assert edge_index.shape[0] == 2
+    assert o_v in ["random", "degree", "coarsen"]
+    assert o_n in ["asc", "desc", "random"]
+    global last_stats
+    dev = _device_for(edge_index)
+    lib, h = _handle(dev)
+    with torch.cuda.device(dev):
+        row, col, w, E = _prep_edges(edge_index, edge_weights, dev)
+        n = int(num_nodes)
+        d_perm = None
+        if o_v == "random":
+            if perm is None:
+                gen = None
+                if seed is not None:
+                    gen = torch.Generator()
+                    gen.manual_seed(int(seed) & (2**63 - 1))
+                perm = torch.randperm(n, generator=gen)
+            d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+            assert d_perm.numel() == n
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v == "coarsen") else 0
+        out = torch.empty((max(E, 1), 3), dtype=torch.float64, device=dev)
+        rows = ctypes.c_int64(0)
+        st = _lib.Stats()
+        rc = lib.rlap_approx_chol(
+            h, row.data_ptr(), col.data_ptr(), w.data_ptr() if w is not None else None, E, n, int(num_remove),
+            O_V[o_v], O_N[o_n], d_perm.data_ptr() if d_perm is not None else None, shuffle_seed,
+            out.data_ptr(), out.shape[0], ctypes.byref(rows), ctypes.byref(st))
+        if rc != 0:
+            _raise(rc)
+        last_stats = st.as_dict()
+        res = out[: rows.value]
+    if return_device is None or return_device == "same":
+        return res.clone() if res.shape[0] != out.shape[0] else res
+    return res.to(return_device)
+
+
+def approximate_cholesky_batched(
+    edge_index: Tensor,
+    edge_weights: Optional[Tensor],
+    node_ptr: Union[Tensor, Sequence[int]],
+    num_remove: Union[Tensor, Sequence[int]],
+    o_v: str,
+    o_n: str,
+    *,
+    perm: Optional[Tensor] = None,
+    seed: Optional[int] = None,
+    return_device: Optional[Union[str, torch.device]] = None,
+) -> Tuple[Tensor, Tensor]:
+    """Batched-graph mode: graph g owns node ids [node_ptr[g], node_ptr[g+1]).
+
+    Every graph is eliminated independently -- what G separate reference calls would
+    return, concatenated, with global node ids.  Returns (sc_edge_info, row_ptr[G+1]).
+    `perm` concatenates per-graph permutations of LOCAL ids.
+    """
+    assert edge_index.shape[0] == 2
+    assert o_v in ["random", "degree", "coarsen"]
+    assert o_n in ["asc", "desc", "random"]
+    global last_stats
+    dev = _device_for(edge_index)
+    lib, h = _handle(dev)
+    np_ = torch.as_tensor(node_ptr, dtype=torch.int64).cpu().contiguous()
+    nr_ = torch.as_tensor(num_remove, dtype=torch.int64).cpu().contiguous()
+    G = np_.numel() - 1
+    assert nr_.numel() == G
+    with torch.cuda.device(dev):
+        row, col, w, E = _prep_edges(edge_index, edge_weights, dev)
+        N = int(np_[-1])
+        d_perm = None
+        if o_v == "random":
+            if perm is None:
+                gen = torch.Generator()
+                gen.manual_seed(_seed_from(seed) & (2**63 - 1))
+                perm = torch.cat([torch.randperm(int(np_[g + 1] - np_[g]), generator=gen) for g in range(G)]) if G else torch.empty(0, dtype=torch.int64)
+            d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+            assert d_perm.numel() == N
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v == "coarsen") else 0
+        out = torch.empty((max(E, 1), 3), dtype=torch.float64, device=dev)
+        row_ptr = torch.zeros(G + 1, dtype=torch.int64)
+        st = _lib.Stats()
+        rc = lib.rlap_approx_chol_batched(
+            h, row.data_ptr(), col.data_ptr(), w.data_ptr() if w is not None else None, E, G,
+            np_.data_ptr(), nr_.data_ptr(), O_V[o_v], O_N[o_n],
+            d_perm.data_ptr() if d_perm is not None else None, shuffle_seed,
+            out.data_ptr(), out.shape[0], row_ptr.data_ptr(), ctypes.byref(st))
+        if rc != 0:
+            _raise(rc)
+        last_stats = st.as_dict()
+        res = out[: int(row_ptr[-1])]
+    if return_device is not None and return_device != "same":
+        res = res.to(return_device)
+    return res, row_ptr
+
+
+def identity(a: Tensor) -> Tensor:
+    """Boundary self-test (reference: rlap/ops.py:61-63): tensor -> column-major
+    staging -> tensor, on the GPU; returns a tensor on `a`'s device."""
+    assert a.dim() == 2
+    dev = _device_for(a)
+    lib, h = _handle(dev)
+    with torch.cuda.device(dev):
+        x = a.to(device=dev, dtype=torch.float64).contiguous()
+        tmp = torch.empty_like(x)
+        out = torch.empty_like(x)
+        rc = lib.rlap_identity(h, x.data_ptr(), tmp.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1])
+        if rc != 0:
+            _raise(rc)
+    return out.to(a.device)
+
+
+def rng_uniforms(count: int, device=None) -> Tensor:
+    """First `count` uniforms of the sampling stream as generated on the device."""
+    dev = _device_for(None) if device is None else torch.device(device)
+    lib, h = _handle(dev)
+    with torch.cuda.device(dev):
+        out = torch.empty(count, dtype=torch.float64, device=dev)
+        rc = lib.rlap_rng_uniforms(h, count, out.data_ptr())
+        if rc != 0:
+            _raise(rc)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# torch.ops.extension_cpp.* -- the reference's dispatcher-level interface
+# (py_api_binder.cc:80-88), so third-party code calling the torch op still works.
+# ---------------------------------------------------------------------------
+def _op_approximate_cholesky(edge_info: Tensor, num_nodes: int, num_remove: int, o_v: str, o_n: str) -> Tensor:
+    ei = edge_info
+    edge_index = ei[:, :2].t().to(torch.int64)
+    res = approximate_cholesky(edge_index, ei[:, 2], num_nodes, num_remove, o_v, o_n,
+                               return_device="cpu" if not ei.is_cuda else "same")
+    return res
+
+
+def _op_identity(a: Tensor) -> Tensor:
+    return identity(a)
+
+
+def _register_torch_ops():
+    try:
+        lib = torch.library.Library("extension_cpp", "DEF")
+        lib.define("approximate_cholesky(Tensor edge_info, int num_nodes, int num_remove, str o_v,  str o_n) -> Tensor")
+        lib.define("identity(Tensor a) -> Tensor")
+    except RuntimeError:
+        return None  # namespace already defined (e.g. the reference extension is loaded too)
+    for key in ("CPU", "CUDA"):
+        lib.impl("approximate_cholesky", _op_approximate_cholesky, key)
+        lib.impl("identity", _op_identity, key)
+    return lib
+
+
+_torch_lib = _register_torch_ops()

@@ -1,0 +1,86 @@
+"""CPU checks of the code the HIP kernels share (rlap_amd/csrc/rlap_core.h):
+  * std::sort emulation == libstdc++ std::sort, permutation for permutation;
+  * chunked columns + lazy bucket-stack PQ + sequential elimination == oracle, bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from util import ba_graph, clique, grid2d, path, star, sym_weights
+
+
+def _mperm(lib, fn, keys, desc):
+    k = np.ascontiguousarray(keys, dtype=np.float64)
+    p = np.empty(len(k), dtype=np.int64)
+    getattr(lib, fn)(ctypes.c_void_p(k.ctypes.data), ctypes.c_int64(len(k)), ctypes.c_int(desc), ctypes.c_void_p(p.ctypes.data))
+    return p
+
+
+def test_std_sort_emulation_matches_libstdcxx(host_mirror):
+    rng = np.random.RandomState(0)
+    for trial in range(600):
+        n = int(rng.choice([1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 40, 64, 65, 100, 257, 1000, 3000]))
+        kind = trial % 5
+        if kind == 0:
+            k = np.ones(n)
+        elif kind == 1:
+            k = rng.randint(0, 3, size=n).astype(float)
+        elif kind == 2:
+            k = rng.rand(n)
+        elif kind == 3:
+            k = np.sort(rng.randint(0, n // 4 + 1, size=n)).astype(float)
+        else:
+            k = np.sort(rng.randint(0, n // 4 + 1, size=n))[::-1].astype(float)
+        for desc in (0, 1):
+            assert np.array_equal(oracle.stdsort_perm(k, bool(desc)), _mperm(host_mirror, "mirror_sort_perm", k, desc))
+
+
+def test_heap_sort_fallback_matches_partial_sort(host_mirror):
+    rng = np.random.RandomState(1)
+    for t in range(400):
+        n = int(rng.choice([2, 3, 4, 5, 17, 18, 33, 100, 1001]))
+        k = rng.randint(0, max(2, n // 3), size=n).astype(float) if t % 2 else rng.rand(n)
+        for d in (0, 1):
+            assert np.array_equal(oracle.heapsort_perm(k, bool(d)), _mperm(host_mirror, "mirror_heapsort_perm", k, d))
+
+
+def _mirror(lib, ei, w, n, t, o_v, o_n, perm=None, seed=0):
+    E = ei.shape[1]
+    row = np.ascontiguousarray(ei[0])
+    col = np.ascontiguousarray(ei[1])
+    w = np.ones(E) if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    out = ctypes.POINTER(ctypes.c_double)()
+    rows = ctypes.c_int64()
+    order = np.full(max(n, 1), -1, dtype=np.int64)
+    p = np.ascontiguousarray(perm, dtype=np.int64) if perm is not None else None
+    rc = lib.mirror_approx_chol(
+        ctypes.c_void_p(row.ctypes.data), ctypes.c_void_p(col.ctypes.data), ctypes.c_void_p(w.ctypes.data),
+        ctypes.c_int64(E), ctypes.c_int64(n), ctypes.c_int64(t), oracle.O_V[o_v], oracle.O_N[o_n],
+        ctypes.c_void_p(p.ctypes.data) if p is not None else None, ctypes.c_uint64(seed), ctypes.c_int32(4 * E + 64),
+        ctypes.byref(out), ctypes.byref(rows), ctypes.c_void_p(order.ctypes.data))
+    assert rc == 0
+    m = rows.value
+    res = np.ctypeslib.as_array(out, shape=(max(m, 1) * 3,))[: 3 * m].copy().reshape(m, 3)
+    lib.mirror_free(out)
+    return res, order[:n]
+
+
+GRAPHS = [("K6", clique(6), 6), ("P9", path(9), 9), ("star7", star(7), 7), ("grid5x6", grid2d(5, 6), 30),
+          ("BA100_50", ba_graph(100, 50, 0), 100), ("BA500_3", ba_graph(500, 3, 1), 500)]
+
+
+@pytest.mark.parametrize("o_v", ["degree", "random", "coarsen"])
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_device_data_structures_match_oracle(host_mirror, o_v, o_n):
+    for name, ei, n in GRAPHS:
+        perm = np.random.RandomState(7).permutation(n) if o_v == "random" else None
+        for t in sorted({0, 1, n // 2, n - 1, n + 5}):
+            a, oa = oracle.approximate_cholesky(ei, None, n, t, o_v, o_n, perm=perm, shuffle_seed=3, return_order=True)
+            b, ob = _mirror(host_mirror, ei, None, n, t, o_v, o_n, perm=perm, seed=3)
+            assert np.array_equal(oa, ob), (name, t)
+            assert a.shape == b.shape and np.array_equal(a, b), (name, t)
+        w = sym_weights(ei, n, 5)
+        a = oracle.approximate_cholesky(ei, w, n, n // 2, o_v, o_n, perm=perm, shuffle_seed=4)
+        b, _ = _mirror(host_mirror, ei, w, n, n // 2, o_v, o_n, perm=perm, seed=4)
+        assert np.array_equal(a, b), name
