@@ -51,7 +51,8 @@ struct rlap_handle_s {
     // setup
     DevBuf node_ptr_d, vgraph, flags, acc, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, gcol;
     // graph state
-    DevBuf e_nbr, e_val, e_twin, app_cnt, app_chunk, key, pqpos, bhead, ocur, oend, origpos, orig_order, log_v, log_prev, gd_d, pool_top;
+    DevBuf e_nbr, e_val, e_twin, app_cnt, app_chunk, key, pqpos, ocur, oend, origpos, orig_order, gd_d, pool_top;
+    DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, tcount;
     DevBuf skey0, skey1, sval0, sval1;
     DevBuf rng;
     int64_t rng_len = 0;
@@ -207,8 +208,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         max_nnz_g = std::max(max_nnz_g, nnz_g);
         D.vbase = (int32_t)c.h_node_ptr[g]; D.n = (int32_t)n; D.t = c.h_t[g];
         D.bucket_base = (int32_t)bucket_total; bucket_total += 2 * n + 1;
-        int64_t lc = (int64_t)(h->log_factor * nnz_g) + 2 * n + 64;
-        D.log_base = (int32_t)log_total; D.log_cap = (int32_t)lc; log_total += lc;
+        log_total += (int64_t)(h->log_factor * nnz_g) + (int64_t)BCH0 * (2 * n + 1) + 64;
         int64_t sc = nnz_g / 2 + 8;
         D.scr_base = (int32_t)scr_total; D.scr_cap = (int32_t)sc; scr_total += sc;
         int64_t ne = std::max<int64_t>(0, std::min<int64_t>(c.h_t[g], n - 1));
@@ -216,7 +216,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         nelim_total += ne;
         surv_base[g + 1] = surv_base[g] + (n - ne);
     }
-    if (bucket_total >= ((int64_t)1 << 31) || log_total >= ((int64_t)1 << 31) || scr_total >= ((int64_t)1 << 31)) return RLAP_E_TOO_LARGE;
+    if (bucket_total * BDIR >= ((int64_t)1 << 40) || bucket_total >= ((int64_t)1 << 31) || log_total >= ((int64_t)1 << 31) || scr_total >= ((int64_t)1 << 31)) return RLAP_E_TOO_LARGE;
     const int64_t S = surv_base[G];
     st.n_eliminated = nelim_total;
     ENSURE(h->gd_d, sizeof(GraphDesc) * G);
@@ -225,10 +225,16 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     // ---------------- PQ init ----------------
     ENSURE(h->app_cnt, 4 * N); ENSURE(h->app_chunk, 4 * N); ENSURE(h->key, 4 * N); ENSURE(h->pqpos, 4 * N);
     ENSURE(h->origpos, 4 * N);
-    ENSURE(h->bhead, 4 * bucket_total); ENSURE(h->ocur, 4 * bucket_total); ENSURE(h->oend, 4 * bucket_total);
+    ENSURE(h->ocur, 4 * bucket_total); ENSURE(h->oend, 4 * bucket_total);
+    ENSURE(h->bs_cnt, 4 * bucket_total); ENSURE(h->bs_alloc, 4 * bucket_total); ENSURE(h->bs_dir, 4 * bucket_total * BDIR);
+    ENSURE(h->bs_v, 4 * log_total); ENSURE(h->bs_id, 4 * log_total); ENSURE(h->bs_pool_top, 4);
+    ENSURE(h->batch_pos, 4 * N); ENSURE(h->tcount, 4 * N);
     ENSURE(h->skey0, 8 * N); ENSURE(h->skey1, 8 * N); ENSURE(h->sval0, 4 * N); ENSURE(h->sval1, 4 * N);
-    ENSURE(h->log_v, 4 * log_total); ENSURE(h->log_prev, 4 * log_total);
-    HIPCHK(hipMemsetAsync(h->bhead.p, 0xFF, 4 * bucket_total, s));
+    HIPCHK(hipMemsetAsync(h->bs_cnt.p, 0, 4 * bucket_total, s));
+    HIPCHK(hipMemsetAsync(h->bs_alloc.p, 0, 4 * bucket_total, s));
+    HIPCHK(hipMemsetAsync(h->bs_pool_top.p, 0, 4, s));
+    HIPCHK(hipMemsetAsync(h->batch_pos.p, 0xFF, 4 * N, s));
+    HIPCHK(hipMemsetAsync(h->tcount.p, 0, 4 * N, s));
     HIPCHK(hipMemsetAsync(h->ocur.p, 0, 4 * bucket_total, s));
     HIPCHK(hipMemsetAsync(h->oend.p, 0, 4 * bucket_total, s));
     hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->vgraph.as<int32_t>(), (int32_t)N, h->key.as<int32_t>(),
@@ -254,9 +260,11 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     A.slot_cap = (int32_t)slot_cap; A.pool_top = h->pool_top.as<int32_t>();
     A.app_cnt = h->app_cnt.as<int32_t>(); A.app_chunk = h->app_chunk.as<int32_t>();
     A.key = h->key.as<int32_t>(); A.pqpos = h->pqpos.as<int32_t>();
-    A.bhead = h->bhead.as<int32_t>(); A.ocur = h->ocur.as<int32_t>(); A.oend = h->oend.as<int32_t>();
+    A.ocur = h->ocur.as<int32_t>(); A.oend = h->oend.as<int32_t>();
     A.orig_order = h->orig_order.as<int32_t>();
-    A.log_v = h->log_v.as<int32_t>(); A.log_prev = h->log_prev.as<int32_t>();
+    A.bs_cnt = h->bs_cnt.as<int32_t>(); A.bs_alloc = h->bs_alloc.as<int32_t>(); A.bs_dir = h->bs_dir.as<int32_t>();
+    A.bs_v = h->bs_v.as<int32_t>(); A.bs_id = h->bs_id.as<int32_t>();
+    A.bs_pool_top = h->bs_pool_top.as<int32_t>(); A.bs_pool_cap = (int32_t)log_total;
     A.rng = h->rng.as<double>(); A.rng_len = h->rng_len;
     A.perm = c.d_perm; A.o_v = c.o_v; A.o_n = c.o_n; A.shuffle_seed = c.seed;
     ElimScratch ES;
@@ -264,7 +272,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
 
     if (h->timing) HIPCHK(hipEventRecord(h->ev[1], s));
     // ---------------- elimination ----------------
-    hipLaunchKernelGGL(k_eliminate, dim3((unsigned)G), dim3(64), 0, s, A, h->gd_d.as<GraphDesc>(), ES);
+    hipLaunchKernelGGL(k_eliminate_batch, dim3((unsigned)G), dim3(256), 0, s, A, h->gd_d.as<GraphDesc>(), ES,
+                       h->batch_pos.as<int32_t>(), h->tcount.as<int32_t>());
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
     HIPCHK(hipMemcpyAsync(gd.data(), h->gd_d.p, sizeof(GraphDesc) * G, hipMemcpyDeviceToHost, s));
@@ -381,7 +390,7 @@ int rlap_destroy(rlap_handle h) {
     if (!h) return RLAP_OK;
     DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->flags, &h->acc, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
                       &h->deg, &h->colptr, &h->slot_col, &h->gcol, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
-                      &h->bhead, &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->log_v, &h->log_prev, &h->gd_d, &h->pool_top, &h->skey0,
+                      &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->tcount, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
                       &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters};
     for (DevBuf* b : bufs) b->release();

@@ -109,13 +109,14 @@ RLAP_HD bool srec_less(const SRec& a, const SRec& b) {
     return GREATER ? (a.key > b.key) : (a.key < b.key);
 }
 
-template <bool GREATER, class P>
-RLAP_HD void ss_adjust_heap(P a, int first, int hole, int len, SRec value) {
+// Generic form: T = element type, less(const T&, const T&) strict weak order.
+template <class T, class Less, class P>
+RLAP_HD void gs_adjust_heap(P a, int first, int hole, int len, T value, Less less) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (srec_less<GREATER>(a[first + child], a[first + child - 1])) child--;
+        if (less(a[first + child], a[first + child - 1])) child--;
         a[first + hole] = a[first + child];
         hole = child;
     }
@@ -125,7 +126,7 @@ RLAP_HD void ss_adjust_heap(P a, int first, int hole, int len, SRec value) {
         hole = child - 1;
     }
     int parent = (hole - 1) / 2;
-    while (hole > top && srec_less<GREATER>(a[first + parent], value)) {
+    while (hole > top && less(a[first + parent], value)) {
         a[first + hole] = a[first + parent];
         hole = parent;
         parent = (hole - 1) / 2;
@@ -133,14 +134,14 @@ RLAP_HD void ss_adjust_heap(P a, int first, int hole, int len, SRec value) {
     a[first + hole] = value;
 }
 
-template <bool GREATER, class P>
-RLAP_HD void ss_heap_sort(P a, int first, int last) {  // __partial_sort(first,last,last)
+template <class T, class Less, class P>
+RLAP_HD void gs_heap_sort(P a, int first, int last, Less less) {  // __partial_sort(first,last,last)
     int len = last - first;
     if (len >= 2) {
         int parent = (len - 2) / 2;
         while (true) {
-            SRec v = a[first + parent];
-            ss_adjust_heap<GREATER>(a, first, parent, len, v);
+            T v = a[first + parent];
+            gs_adjust_heap<T>(a, first, parent, len, v, less);
             if (parent == 0) break;
             parent--;
         }
@@ -148,15 +149,15 @@ RLAP_HD void ss_heap_sort(P a, int first, int last) {  // __partial_sort(first,l
     int l = last;
     while (l - first > 1) {
         --l;
-        SRec v = a[l];
+        T v = a[l];
         a[l] = a[first];
-        ss_adjust_heap<GREATER>(a, first, 0, l - first, v);
+        gs_adjust_heap<T>(a, first, 0, l - first, v, less);
     }
 }
 
 // introsort phase only (everything before __final_insertion_sort)
-template <bool GREATER, class P>
-RLAP_HD void ss_introsort_loop(P a, int n) {
+template <class T, class Less, class P>
+RLAP_HD void gs_introsort_loop(P a, int n, Less less) {
     if (n <= 16) return;
     int depth0 = 0;
     for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
@@ -169,28 +170,28 @@ RLAP_HD void ss_introsort_loop(P a, int n) {
         --sp;
         int first = stk_first[sp], last = stk_last[sp], depth = stk_depth[sp];
         while (last - first > 16) {
-            if (depth == 0) { ss_heap_sort<GREATER>(a, first, last); break; }
+            if (depth == 0) { gs_heap_sort<T>(a, first, last, less); break; }
             --depth;
             // __move_median_to_first(first, first+1, mid, last-1)
             int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
             int pick;
-            if (srec_less<GREATER>(a[ia], a[ib])) {
-                if (srec_less<GREATER>(a[ib], a[ic])) pick = ib;
-                else if (srec_less<GREATER>(a[ia], a[ic])) pick = ic;
+            if (less(a[ia], a[ib])) {
+                if (less(a[ib], a[ic])) pick = ib;
+                else if (less(a[ia], a[ic])) pick = ic;
                 else pick = ia;
-            } else if (srec_less<GREATER>(a[ia], a[ic])) pick = ia;
-            else if (srec_less<GREATER>(a[ib], a[ic])) pick = ic;
+            } else if (less(a[ia], a[ic])) pick = ia;
+            else if (less(a[ib], a[ic])) pick = ic;
             else pick = ib;
-            { SRec t = a[first]; a[first] = a[pick]; a[pick] = t; }
+            { T t = a[first]; a[first] = a[pick]; a[pick] = t; }
             // __unguarded_partition(first+1, last, pivot=first)
-            SRec pv = a[first];
+            T pv = a[first];
             int f = first + 1, l = last;
             while (true) {
-                while (srec_less<GREATER>(a[f], pv)) ++f;
+                while (less(a[f], pv)) ++f;
                 --l;
-                while (srec_less<GREATER>(pv, a[l])) --l;
+                while (less(pv, a[l])) --l;
                 if (!(f < l)) break;
-                SRec t = a[f]; a[f] = a[l]; a[l] = t;
+                T t = a[f]; a[f] = a[l]; a[l] = t;
                 ++f;
             }
             int cut = f;
@@ -203,22 +204,33 @@ RLAP_HD void ss_introsort_loop(P a, int n) {
 
 // __final_insertion_sort == stable insertion sort of the whole range (the
 // unguarded part never runs past the sentinel left by the partitions).
-template <bool GREATER, class P>
-RLAP_HD void ss_insertion_sort(P a, int n) {
+template <class T, class Less, class P>
+RLAP_HD void gs_insertion_sort(P a, int n, Less less) {
     for (int i = 1; i < n; ++i) {
-        SRec v = a[i];
+        T v = a[i];
         int j = i - 1;
-        while (j >= 0 && srec_less<GREATER>(v, a[j])) { a[j + 1] = a[j]; --j; }
+        while (j >= 0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
         a[j + 1] = v;
     }
 }
 
-template <bool GREATER, class P>
-RLAP_HD void std_sort_emul(P a, int n) {
+template <class T, class Less, class P>
+RLAP_HD void gs_std_sort(P a, int n, Less less) {
     if (n < 2) return;
-    ss_introsort_loop<GREATER>(a, n);
-    ss_insertion_sort<GREATER>(a, n);
+    gs_introsort_loop<T>(a, n, less);
+    gs_insertion_sort<T>(a, n, less);
 }
+
+template <bool GREATER>
+struct SRecLess {
+    RLAP_HD bool operator()(const SRec& x, const SRec& y) const { return GREATER ? (x.key > y.key) : (x.key < y.key); }
+};
+
+template <bool GREATER, class P>
+RLAP_HD void ss_heap_sort(P a, int first, int last) { gs_heap_sort<SRec>(a, first, last, SRecLess<GREATER>()); }
+
+template <bool GREATER, class P>
+RLAP_HD void std_sort_emul(P a, int n) { gs_std_sort<SRec>(a, n, SRecLess<GREATER>()); }
 
 // Key of the injected "random" neighbour order: a 52-bit hash, exact in a double.
 // The order itself is std::sort (emulated) ascending on this key, applied to the
@@ -232,14 +244,14 @@ struct GraphDesc {      // one per graph of a batch
     int32_t vbase;      // global id of local vertex 0
     int32_t n;          // vertices
     int64_t t;          // num_remove
-    int32_t bucket_base;  // into bhead/ocur/oend, 2n+1 buckets
-    int32_t log_base;   // into log_v/log_prev
-    int32_t log_cap;
+    int32_t bucket_base;  // into bs_cnt/bs_alloc/bs_dir/ocur/oend, 2n+1 buckets
+    int32_t pad0;
+    int32_t pad1;
     int32_t scr_base;   // big-column scratch, in entries
     int32_t scr_cap;
     // running state / results
     int32_t minlist;
-    int32_t log_cnt;
+    int32_t push_cnt;   // ids handed to PQ pushes so far (pqpos values)
     int32_t n_elim;
     int32_t status;
     int64_t n_draws;
@@ -261,9 +273,13 @@ struct Arrays {
     int32_t* pool_top;       // next free slot (device counter)
     int32_t* app_cnt; int32_t* app_chunk;            // [N]
     int32_t* key; int32_t* pqpos;                    // [N]; pqpos -1 = original place, >=0 log entry, -2 popped
-    int32_t* bhead; int32_t* ocur; int32_t* oend;    // [sum(2n+1)]
+    int32_t* ocur; int32_t* oend;                    // [sum(2n+1)] never-moved members of each bucket
+    // per-bucket LIFO stacks of moved vertices (geometric chunks, per-bucket directory)
+    int32_t* bs_cnt; int32_t* bs_alloc;              // [sum(2n+1)] height, chunks allocated
+    int32_t* bs_dir;                                 // [sum(2n+1) * BDIR] chunk base in the bs pool
+    int32_t* bs_v; int32_t* bs_id;                   // [bs_pool_cap] entry = (vertex, push id)
+    int32_t* bs_pool_top; int32_t bs_pool_cap;
     const int32_t* orig_order;                       // [N] global ids by (graph, deg asc, id desc)
-    int32_t* log_v; int32_t* log_prev;
     const double* rng; int64_t rng_len;
     const int64_t* perm;     // [N] local ids (o_v random), graph g at [vbase, vbase+n)
     int32_t o_v; int32_t o_n;
@@ -325,20 +341,65 @@ RLAP_HD int32_t serial_gather(const Arrays& A, int32_t v, const ColBuf& B, int32
     return len;
 }
 
-// Lazy bucket stacks == the reference's doubly linked bucket lists
-// (preconditioner.cc:125-190): newest move first, then never-moved vertices
-// in descending id. Stale entries (vertex moved again / popped) are skipped.
+// Bucket stacks == the reference's doubly linked bucket lists
+// (preconditioner.cc:125-246): a move re-inserts the vertex at the bucket head,
+// so a bucket pops its moved vertices newest first, then its never-moved
+// vertices in descending id.  An entry is stale once the vertex moved again or
+// was popped (pqpos != id); stale entries are dropped when they reach the top.
+constexpr int BCH0 = 16;   // capacity of a bucket stack's first chunk
+constexpr int BDIR = 26;   // directory entries per bucket (covers 2^30 entries)
+RLAP_HD int bs_chunk_of(int a) {
+    unsigned q = (unsigned)a / BCH0 + 1u;
+    int c = 0;
+    while (q > 1u) { q >>= 1; ++c; }
+    return c;
+}
+RLAP_HD int bs_chunk_start(int c) { return BCH0 * ((1 << c) - 1); }
+RLAP_HD int bs_chunk_cap(int c) { return BCH0 << c; }
+// pool slot of entry `a` of bucket `b` (global bucket index); chunk must exist
+RLAP_HD int32_t bs_slot(const Arrays& A, int32_t b, int32_t a) {
+    int c = bs_chunk_of(a);
+    return A.bs_dir[(int64_t)b * BDIR + c] + (a - bs_chunk_start(c));
+}
+// make sure the chunk holding entry `a` of bucket b exists; returns false on pool overflow
+RLAP_HD bool bs_ensure(const Arrays& A, int32_t b, int32_t a) {
+    int c = bs_chunk_of(a);
+    int32_t have = A.bs_alloc[b];
+    while (have <= c) {
+        int32_t need = bs_chunk_cap(have);
+        int32_t base = pool_take(A.bs_pool_top, need);
+        if (base < 0 || base > A.bs_pool_cap - need) return false;
+        A.bs_dir[(int64_t)b * BDIR + have] = base;
+        ++have;
+    }
+    A.bs_alloc[b] = have;
+    return true;
+}
+
+RLAP_HD int pq_push(const Arrays& A, GraphDesc& G, int32_t v, int32_t lst) {
+    int32_t b = G.bucket_base + lst;
+    int32_t a = A.bs_cnt[b];
+    if (!bs_ensure(A, b, a)) return ST_LOG_OVERFLOW;
+    int32_t s = bs_slot(A, b, a);
+    int32_t id = G.push_cnt++;
+    A.bs_v[s] = v; A.bs_id[s] = id;
+    A.bs_cnt[b] = a + 1;
+    A.pqpos[v] = id;
+    if (lst < G.minlist) G.minlist = lst;
+    return ST_OK;
+}
+
 RLAP_HD int32_t pq_pop(const Arrays& A, GraphDesc& G) {
     while (true) {
         int32_t b = G.bucket_base + G.minlist;
-        int32_t e = A.bhead[b];
-        while (e >= 0) {
-            int32_t v = A.log_v[G.log_base + e];
-            int32_t pe = A.log_prev[G.log_base + e];
-            if (A.pqpos[v] == e) { A.bhead[b] = pe; A.pqpos[v] = -2; return v; }
-            e = pe;
+        int32_t cnt = A.bs_cnt[b];
+        while (cnt > 0) {
+            int32_t s = bs_slot(A, b, cnt - 1);
+            --cnt;
+            int32_t v = A.bs_v[s];
+            if (A.pqpos[v] == A.bs_id[s]) { A.bs_cnt[b] = cnt; A.pqpos[v] = -2; return v; }
         }
-        A.bhead[b] = -1;
+        A.bs_cnt[b] = 0;
         int32_t oc = A.ocur[b], oe = A.oend[b];
         while (oc < oe) {
             int32_t v = A.orig_order[oc++];
@@ -361,15 +422,8 @@ RLAP_HD int pq_commit_serial(const Arrays& A, GraphDesc& G, const ColBuf& B, int
     std_sort_emul<false>(B.rec, cnt);  // distinct keys
     for (int32_t i = 0; i < cnt; ++i) {
         int32_t x = B.rec[i].idx;
-        int32_t v = B.b_nbr[x];
-        int32_t lst = pq_list_of(B.t_key[x], G.n);
-        if (G.log_cnt >= G.log_cap) return ST_LOG_OVERFLOW;
-        int32_t e = G.log_cnt++;
-        A.log_v[G.log_base + e] = v;
-        A.log_prev[G.log_base + e] = A.bhead[G.bucket_base + lst];
-        A.bhead[G.bucket_base + lst] = e;
-        A.pqpos[v] = e;
-        if (lst < G.minlist) G.minlist = lst;
+        int rc = pq_push(A, G, B.b_nbr[x], pq_list_of(B.t_key[x], G.n));
+        if (rc) return rc;
     }
     return ST_OK;
 }
@@ -510,6 +564,183 @@ RLAP_HD int32_t serial_output(const Arrays& A, const GraphDesc& G, const ColBuf&
         o[0] = (double)B.a_nbr[j]; o[1] = (double)v; o[2] = B.a_val[j];
     }
     return m;
+}
+
+
+// ---------------------------------------------------------------------------
+// Batch ("frontier") elimination: the next B pops of the sequential order are
+// prepared side by side and committed as the longest prefix whose members are
+// pairwise non-adjacent and that no PQ move pre-empts -- exactly the sequential
+// result, with the RNG offsets handed out by a prefix sum.
+// Per-candidate state lives in one record (LDS on the device).
+// ---------------------------------------------------------------------------
+constexpr int BCAP = 32;   // live entries a batch candidate may have; longer ones take the single-vertex path
+
+struct TRes {     // per-target PQ replay result, stored over Ent::aux
+    int32_t key_after;
+    int16_t mv;   // op number of the target's last bucket move by this candidate, -1 none
+    uint8_t c;    // pushes into the target's column (= Incs)
+    uint8_t flags;
+};
+struct Ent {
+    double val;   // weight; after sampling: the new edge weight of position j
+    union {
+        double aux;   // keyed-order key / cumulative weight ...
+        TRes res;     // ... after sampling: the replay result
+    };
+    int32_t nbr;
+    int32_t twin;
+};
+enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8 };
+enum { TF_CONTENDED = 1 };
+
+struct Cand {
+    Ent e[BCAP];
+    uint8_t ksel[BCAP];
+    int32_t v;
+    int32_t m;        // live (= distinct) neighbours
+    int32_t flags;
+    int32_t src;      // >= 0: bucket-stack index it was read from; < 0: ~(index into orig_order)
+    int64_t draw0;    // first uniform
+    int32_t ndraw;
+    int32_t koff;     // coarsen: chosen position
+};
+
+RLAP_HD TRes& ent_tres(Ent& e) { return e.res; }
+
+struct EntLessNbr { RLAP_HD bool operator()(const Ent& x, const Ent& y) const { return x.nbr < y.nbr; } };
+struct EntLessVal { RLAP_HD bool operator()(const Ent& x, const Ent& y) const { return x.val < y.val; } };
+struct EntGreaterVal { RLAP_HD bool operator()(const Ent& x, const Ent& y) const { return x.val > y.val; } };
+struct EntLessAux { RLAP_HD bool operator()(const Ent& x, const Ent& y) const { return x.aux < y.aux; } };
+
+// gather (reference traversal order) -> sort by id -> (no multi-edges allowed) -> order by o_n
+RLAP_HD void cand_prepare(const Arrays& A, int32_t v, Cand& C) {
+    C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0;
+    int32_t len = 0;
+    bool big = false;
+    int32_t a = A.app_cnt[v];
+    if (a > 0) {
+        int32_t base = A.app_chunk[v];
+        int c = chunk_of(a - 1);
+        int32_t idx = a - 1;
+        while (idx >= 0 && !big) {
+            int32_t cs = chunk_start(c);
+            for (int32_t t = idx; t >= cs; --t) {
+                int32_t s = base + 1 + (t - cs);
+                double val = A.e_val[s];
+                if (val > 0) {
+                    if (len >= BCAP) { big = true; break; }
+                    C.e[len].val = val; C.e[len].nbr = A.e_nbr[s]; C.e[len].twin = A.e_twin[s]; C.e[len].aux = 0;
+                    ++len;
+                }
+            }
+            idx = cs - 1;
+            base = A.e_nbr[base];
+            --c;
+        }
+    }
+    if (!big) {
+        int32_t cp0 = A.colptr[v];
+        for (int32_t s = A.colptr[v + 1] - 1; s >= cp0; --s) {
+            double val = A.e_val[s];
+            if (val > 0) {
+                if (len >= BCAP) { big = true; break; }
+                C.e[len].val = val; C.e[len].nbr = A.e_nbr[s]; C.e[len].twin = A.e_twin[s]; C.e[len].aux = 0;
+                ++len;
+            }
+        }
+    }
+    if (big) { C.flags = CF_BIG; return; }
+    C.m = len;
+    gs_std_sort<Ent>(C.e, len, EntLessNbr());
+    for (int32_t i = 1; i < len; ++i) if (C.e[i].nbr == C.e[i - 1].nbr) { C.flags = CF_DUP; return; }
+    if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
+        uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
+        for (int32_t i = 0; i < len; ++i) C.e[i].aux = keyed_order_dkey(kb, C.e[i].nbr);
+        gs_std_sort<Ent>(C.e, len, EntLessAux());
+    } else if (A.o_n == ON_ASC) {
+        gs_std_sort<Ent>(C.e, len, EntLessVal());
+    } else {
+        gs_std_sort<Ent>(C.e, len, EntGreaterVal());
+    }
+    C.ndraw = (A.o_v == OV_COARSEN) ? (len >= 1 ? 1 : 0) : (len > 1 ? len - 1 : 0);
+}
+
+RLAP_HD int32_t ent_upper_index(const Ent* e, int32_t m, double r) {  // first a with cum[a] > r, else m-1
+    int32_t lo = 0, hi = m;
+    while (lo < hi) {
+        int32_t mid = (lo + hi) >> 1;
+        if (e[mid].aux > r) hi = mid; else lo = mid + 1;
+    }
+    return lo < m ? lo : m - 1;
+}
+
+// cumulative weights, the f/colScale/wdeg recurrences and the sampled targets
+// (:366-417 | :856-897).  Leaves the new edge weight of position j in e[j].val.
+RLAP_HD void cand_sample(const Arrays& A, Cand& C) {
+    const int32_t m = C.m;
+    double csum = 0;
+    for (int32_t j = 0; j < m; ++j) { csum += C.e[j].val; C.e[j].aux = csum; }
+    if (A.o_v == OV_COARSEN) {
+        if (m < 1) return;
+        double u = A.rng[C.draw0];
+        double r = u * csum;
+        int32_t koff = ent_upper_index(C.e, m, r);
+        C.koff = koff;
+        double wk = C.e[koff].val;
+        for (int32_t j = 0; j < m; ++j) {
+            if (j == koff) continue;
+            double w = C.e[j].val;
+            C.e[j].val = (wk * w) / (wk + w);
+            C.ksel[j] = (uint8_t)koff;
+        }
+        return;
+    }
+    for (int32_t j = 0; j < m - 1; ++j) {
+        double u = A.rng[C.draw0 + j];
+        double cj = C.e[j].aux;
+        double r = u * (csum - cj) + cj;
+        C.ksel[j] = (uint8_t)ent_upper_index(C.e, m, r);
+    }
+    double wdeg = csum, colScale = 1;
+    for (int32_t j = 0; j < m - 1; ++j) {
+        double w = C.e[j].val * colScale;
+        double f = w / wdeg;
+        double omf = 1 - f;
+        C.e[j].val = f * omf * wdeg;
+        colScale = colScale * omf;
+        wdeg = wdeg * omf * omf;
+    }
+}
+
+// Net PQ effect of candidate C on its target at position j, starting from key0
+// (valid while every intermediate key stays <= n, where each change moves the
+// vertex; otherwise *complex is set).  Returns the new key; *mv = op number of
+// the last move or -1; *cnt = pushes into the target's column.
+RLAP_HD int32_t cand_replay(const Arrays& A, const Cand& C, int32_t j, int32_t key0, int32_t n, bool allow_last_dec,
+                            int* mv, int* cnt, bool* complex) {
+    const int32_t m = C.m;
+    int32_t key = key0;
+    int32_t last_inc = -1, c = 0;
+    *mv = -1;
+    if (A.o_v == OV_COARSEN) {
+        if (j == C.koff) {
+            if (key != 1) { key -= 1; *mv = m; }            // :882, op number m
+            c = m - 1;
+            if (c > 0) {
+                key += c;
+                int32_t lastj = (C.koff == m - 1) ? m - 2 : m - 1;
+                *mv = m + 1 + lastj;                           // :896
+            }
+        }
+    } else {
+        for (int32_t q = 0; q < m - 1; ++q) if (C.ksel[q] == j) { ++c; last_inc = q; }
+        if (c > 0) { key += c; *mv = m + last_inc; }          // :399, op numbers m + q
+        if (j == m - 1 && allow_last_dec && key != 1) { key -= 1; *mv = 2 * m; }  // :427
+    }
+    *cnt = c;
+    if (key0 > n || key0 + c > n) *complex = true;
+    return key;
 }
 
 }  // namespace rlap

@@ -223,8 +223,12 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const int32_
 }
 
 // ---------------------------------------------------------------------------
-// K5-K8: elimination, one wave (= one 64-thread workgroup) per graph.
+// K5-K8: elimination.  One 256-thread workgroup per graph runs rounds of the batch
+// ("frontier") scheme; vertices it cannot take (long columns, multi-edges, keys
+// beyond n) go through the single-vertex wave path or the sequential fallback.
 // ---------------------------------------------------------------------------
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 struct ElimLds {
     SRec rec[ECAP];  // sort records; after ordering re-used as cum[ECAP] + newv[ECAP]
@@ -279,6 +283,7 @@ __device__ __forceinline__ int32_t alloc_in_column(const Arrays& A, int32_t& a, 
     return s;
 }
 
+// Single-vertex path, executed by ONE wave (columns up to ECAP entries, multi-edges, any key range).
 __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
                                int32_t acnt, int32_t abase) {
     const int lane = lane_id();
@@ -320,18 +325,18 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
             len0 += popc64(mask);
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     // ---- sort by neighbour id (std::sort semantics, :275-276) ----
     {
         bool done = wave_rank_sort<false>(L, len0, [&](int i) { return (double)L.a_nbr[i]; }, lane);
-        __syncthreads();
+        WAVE_SYNC();
         if (!done) {
             if (lane == 0) {
                 for (int i = 0; i < len0; ++i) { L.rec[i].key = (double)L.a_nbr[i]; L.rec[i].idx = i; }
                 std_sort_emul<false>(L.rec, len0);
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
     }
 
@@ -374,10 +379,10 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
             }
             L.t_rank[0] = mm;
         }
-        __syncthreads();
+        WAVE_SYNC();
         m = L.t_rank[0];
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     // ---- neighbour metadata (PQ key, append cursor): issued now, used after ordering ----
     for (int x = lane; x < m; x += 64) {
@@ -393,33 +398,33 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
         if (A.o_n == ON_RANDOM || coarsen) {
             uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
             done = wave_rank_sort<false>(L, m, [&](int i) { return keyed_order_dkey(kb, L.b_nbr[i]); }, lane);
-            __syncthreads();
+            WAVE_SYNC();
             if (!done) {
                 if (lane == 0) {
                     for (int i = 0; i < m; ++i) { L.rec[i].key = keyed_order_dkey(kb, L.b_nbr[i]); L.rec[i].idx = i; }
                     std_sort_emul<false>(L.rec, m);
                 }
-                __syncthreads();
+                WAVE_SYNC();
             }
         } else if (A.o_n == ON_ASC) {
             done = wave_rank_sort<false>(L, m, [&](int i) { return L.b_val[i]; }, lane);
-            __syncthreads();
+            WAVE_SYNC();
             if (!done) {
                 if (lane == 0) {
                     for (int i = 0; i < m; ++i) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
                     std_sort_emul<false>(L.rec, m);
                 }
-                __syncthreads();
+                WAVE_SYNC();
             }
         } else {
             done = wave_rank_sort<true>(L, m, [&](int i) { return L.b_val[i]; }, lane);
-            __syncthreads();
+            WAVE_SYNC();
             if (!done) {
                 if (lane == 0) {
                     for (int i = 0; i < m; ++i) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
                     std_sort_emul<true>(L.rec, m);
                 }
-                __syncthreads();
+                WAVE_SYNC();
             }
         }
         for (int j = lane; j < m; j += 64) {
@@ -428,7 +433,7 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
             L.a_slot[j] = L.b_slot[x]; L.a_nbr[j] = L.b_nbr[x]; L.a_val[j] = L.b_val[x]; L.a_twin[j] = L.b_twin[x];
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     double* cum = reinterpret_cast<double*>(L.rec);
     double* newv = cum + ECAP;
@@ -452,11 +457,11 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
             }
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
     const double csum = m > 0 ? cum[m - 1] : 0.0;
     const int64_t draws0 = G.n_draws;
     int ndraw = coarsen ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
-    if (draws0 + ndraw > A.rng_len) { if (lane == 0) G.status = ST_RNG_OVERFLOW; __syncthreads(); return; }
+    if (draws0 + ndraw > A.rng_len) { if (lane == 0) G.status = ST_RNG_OVERFLOW; WAVE_SYNC(); return; }
 
     if (coarsen) {
         if (m >= 1) {
@@ -474,7 +479,7 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
             L.ksel[j] = upper_index(cum, m, r);
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     // ---- per-neighbour: PQ op replay (:291,:399,:427 | :882,:896) + slots for the pushes into its column ----
     const int xk_c = (coarsen && m >= 1) ? L.t_of[koff_c] : -1;
@@ -512,8 +517,8 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
             L.t_list[x] = mv >= 0 ? pq_list_of(key, G.n) : -1;
         }
     }
-    if (__ballot(status != 0) != 0ull) { if (lane == 0) G.status = ST_POOL_OVERFLOW; __syncthreads(); return; }
-    __syncthreads();
+    if (__ballot(status != 0) != 0ull) { if (lane == 0) G.status = ST_POOL_OVERFLOW; WAVE_SYNC(); return; }
+    WAVE_SYNC();
 
     // ---- rewire: twin rewritten in place, new entry appended to column k (:404-414) ----
     if (coarsen) {
@@ -538,95 +543,508 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
 
     // ---- PQ commit: moved neighbours re-enter their bucket at the head, in op order ----
     if (use_pq) {
-        int nmoved_part = 0;
         for (int x = lane; x < m; x += 64) {
             int mvx = L.t_mv[x];
-            int rank = 0;
+            int rank = -1;
             if (mvx >= 0) {
+                rank = 0;
                 for (int y = 0; y < m; ++y) { int mvy = L.t_mv[y]; rank += (mvy >= 0 && mvy < mvx) ? 1 : 0; }
-                nmoved_part += 1;
             }
             L.t_rank[x] = rank;
         }
+        WAVE_SYNC();
+        for (int x = lane; x < m; x += 64) { int r = L.t_rank[x]; if (r >= 0) L.pslot[r] = x; }   // pslot is free now
+        int nmoved_part = 0;
+        for (int x = lane; x < m; x += 64) nmoved_part += (L.t_rank[x] >= 0) ? 1 : 0;
         int nmoved = nmoved_part;
         for (int off = 32; off > 0; off >>= 1) nmoved += __shfl_xor(nmoved, off);
-        __syncthreads();
-        const int32_t log_cnt0 = G.log_cnt;
-        if (log_cnt0 + nmoved > G.log_cap) { if (lane == 0) G.status = ST_LOG_OVERFLOW; __syncthreads(); return; }
-        int minl = 0x7FFFFFFF;
-        // pass 1: predecessor in the same bucket (or the bucket's old head); t_cnt/t_chunk are free now
-        for (int x = lane; x < m; x += 64) {
-            int mvx = L.t_mv[x];
-            if (mvx < 0) continue;
-            int lst = L.t_list[x];
-            int pred = -1, predmv = -1;
-            bool succ = false;
-            for (int y = 0; y < m; ++y) {
-                int mvy = L.t_mv[y];
-                if (mvy < 0 || L.t_list[y] != lst || y == x) continue;
-                if (mvy < mvx) { if (mvy > predmv) { predmv = mvy; pred = y; } } else succ = true;
-            }
-            L.t_cnt[x] = pred >= 0 ? (log_cnt0 + L.t_rank[pred]) : A.bhead[G.bucket_base + lst];
-            L.t_chunk[x] = succ ? 1 : 0;
-            minl = min(minl, lst);
-        }
-        __syncthreads();
-        // pass 2: publish
-        for (int x = lane; x < m; x += 64) {
-            if (L.t_mv[x] < 0) continue;
-            int32_t e = log_cnt0 + L.t_rank[x];
-            int32_t nb = L.b_nbr[x];
-            A.log_v[G.log_base + e] = nb;
-            A.log_prev[G.log_base + e] = L.t_cnt[x];
-            A.pqpos[nb] = e;
-            if (!L.t_chunk[x]) A.bhead[G.bucket_base + L.t_list[x]] = e;
-        }
-        for (int off = 32; off > 0; off >>= 1) minl = min(minl, __shfl_xor(minl, off));
+        WAVE_SYNC();
         if (lane == 0) {
-            G.log_cnt = log_cnt0 + nmoved;
-            if (minl < G.minlist) G.minlist = minl;
+            for (int r = 0; r < nmoved; ++r) {
+                int x = L.pslot[r];
+                int rc = pq_push(A, G, L.b_nbr[x], L.t_list[x]);
+                if (rc) { G.status = rc; break; }
+            }
         }
+        WAVE_SYNC();
+        if (G.status != 0) return;
     }
     if (lane == 0) G.n_draws = draws0 + ndraw;
-    __syncthreads();
+    WAVE_SYNC();
 }
 
-__global__ __launch_bounds__(64) void k_eliminate(Arrays A, GraphDesc* __restrict__ gd, ElimScratch S) {
-    __shared__ ElimLds L;
+
+// ---------------------------------------------------------------------------
+// Batch kernel
+// ---------------------------------------------------------------------------
+constexpr int BATCH = 128;    // candidates per round
+constexpr int MCAP = 2048;    // PQ moves per round (sorted in LDS)
+constexpr int CCAP = 512;     // contended (target, candidate) records per round
+
+struct CRec { int32_t x, i, j; };
+
+struct BatchLds {
+    Cand cand[BATCH];
+    uint64_t mkey[MCAP];
+    int32_t mval[MCAP];
+    int32_t hidx[MCAP];
+    CRec cont[CCAP];
+    CRec csorted[CCAP];
+    int32_t scan[260];
+};
+
+union ElimShared {
+    BatchLds b;
+    ElimLds e;
+};
+
+// exclusive block scan over 256 threads (4 waves); returns exclusive prefix, *total = sum
+__device__ __forceinline__ int block_excl_scan(int val, int* scratch, int* total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = val;
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { int sw = scratch[w]; if (w < wave) base += sw; tot += sw; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - val;
+}
+
+// ordered block compaction helper: position of a flagged thread among flagged threads (thread order)
+__device__ __forceinline__ int block_rank(bool flag, int* scratch, int* total) {
+    return block_excl_scan(flag ? 1 : 0, scratch, total);
+}
+
+__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// rewire stores of one push (preconditioner.cc:404-414)
+__device__ __forceinline__ void rewire_store(const Arrays& A, int32_t s_r, int32_t s_n, int32_t nbr_j, int32_t k, double nw) {
+    A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
+    A.e_nbr[s_n] = nbr_j; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+}
+
+// all pushes of candidate C into the column of its target at position j, in position order
+__device__ __forceinline__ void push_into_target(const Arrays& A, const Cand& C, int32_t j, int32_t& a, int32_t& chunk, int32_t* status) {
+    const int32_t x = C.e[j].nbr;
+    if (A.o_v == OV_COARSEN) {
+        if (j != C.koff) return;
+        for (int32_t p = 0; p < C.m; ++p) {
+            if (p == C.koff) continue;
+            int32_t s_n = alloc_in_column(A, a, chunk, status);
+            if (*status) return;
+            rewire_store(A, C.e[p].twin, s_n, C.e[p].nbr, x, C.e[p].val);
+        }
+    } else {
+        for (int32_t p = 0; p < C.m - 1; ++p) {
+            if (C.ksel[p] != j) continue;
+            int32_t s_n = alloc_in_column(A, a, chunk, status);
+            if (*status) return;
+            rewire_store(A, C.e[p].twin, s_n, C.e[p].nbr, x, C.e[p].val);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __restrict__ gd, ElimScratch S,
+                                                         int32_t* __restrict__ batch_pos, int32_t* __restrict__ tcount) {
+    __shared__ ElimShared sh;
     __shared__ GraphDesc G;
-    __shared__ int32_t s_v;
+    __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status;
+    BatchLds& L = sh.b;
     const int g = blockIdx.x;
-    const int lane = lane_id();
-    if (lane == 0) G = gd[g];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    if (tid == 0) { G = gd[g]; s_status = 0; }
     __syncthreads();
     const int32_t n = G.n;
+    const bool use_pq = A.o_v != OV_RANDOM;
     int64_t nelim = G.t < (int64_t)(n - 1) ? G.t : (int64_t)(n - 1);
     if (nelim < 0) nelim = 0;
-    for (int64_t e1 = 1; e1 <= nelim; ++e1) {
-        int32_t v;
-        if (A.o_v == OV_RANDOM) {
-            v = G.vbase + (int32_t)A.perm[G.vbase + n - e1];
+    int64_t done = 0;
+    int32_t rounds = 0, singles = 0;
+
+    while (done < nelim) {
+        ++rounds;
+        const int32_t Bcur = (int32_t)((nelim - done) < (int64_t)BATCH ? (nelim - done) : (int64_t)BATCH);
+        // ================= P0: predict the next pops =================
+        if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; }
+        __syncthreads();
+        int32_t b = 0;
+        if (use_pq) {
+            while (true) {
+                b = G.bucket_base + G.minlist;
+                const int32_t cnt = A.bs_cnt[b];
+                // moved members, newest first
+                int32_t top = cnt;   // entries [0,top) not yet scanned
+                while (top > 0 && s_nc < Bcur) {
+                    int32_t a = top - 1 - tid;
+                    bool valid = false;
+                    int32_t v = -1;
+                    if (a >= 0) {
+                        int32_t sl = bs_slot(A, b, a);
+                        v = A.bs_v[sl];
+                        valid = (A.pqpos[v] == A.bs_id[sl]);
+                    }
+                    int tot;
+                    int r = block_rank(valid, L.scan, &tot);
+                    int base = s_nc;
+                    __syncthreads();
+                    if (valid && base + r < Bcur) { L.cand[base + r].v = v; L.cand[base + r].src = a; }
+                    if (tid == 0) s_nc = (base + tot < Bcur) ? base + tot : Bcur;
+                    __syncthreads();
+                    top -= 256;
+                }
+                // never-moved members, descending id
+                int32_t oc0 = A.ocur[b];
+                const int32_t oe = A.oend[b];
+                while (oc0 < oe && s_nc < Bcur) {
+                    int32_t oc = oc0 + tid;
+                    bool valid = false;
+                    int32_t v = -1;
+                    if (oc < oe) { v = A.orig_order[oc]; valid = (A.pqpos[v] == -1); }
+                    int tot;
+                    int r = block_rank(valid, L.scan, &tot);
+                    int base = s_nc;
+                    __syncthreads();
+                    if (valid && base + r < Bcur) { L.cand[base + r].v = v; L.cand[base + r].src = ~oc; }
+                    if (tid == 0) s_nc = (base + tot < Bcur) ? base + tot : Bcur;
+                    __syncthreads();
+                    oc0 += 256;
+                }
+                if (s_nc > 0) break;
+                __syncthreads();
+                if (tid == 0) {
+                    A.bs_cnt[b] = 0; A.ocur[b] = oe;
+                    G.minlist += 1;
+                    if (G.minlist > 2 * n) s_status = ST_INTERNAL;
+                }
+                __syncthreads();
+                if (s_status) break;
+            }
+            if (s_status) break;
         } else {
-            if (lane == 0) s_v = pq_pop(A, G);
+            if (tid < Bcur) { L.cand[tid].v = G.vbase + (int32_t)A.perm[G.vbase + n - (done + tid + 1)]; L.cand[tid].src = 0; }
+            if (tid == 0) s_nc = Bcur;
             __syncthreads();
-            v = s_v;
         }
-        int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
-        int32_t acnt = A.app_cnt[v], abase = A.app_chunk[v];
-        if ((cp1 - cp0) + acnt > ECAP) {
-            if (lane == 0) {
-                ColBuf B = S.colbuf(G.scr_base);
-                int rc = serial_eliminate(A, G, B, G.scr_cap, v, e1);
-                if (rc) G.status = rc;
+        const int32_t nc = s_nc;
+
+        // ================= P1: prepare (one thread per candidate) =================
+        if (tid < nc) {
+            int32_t v = L.cand[tid].v, src = L.cand[tid].src;
+            cand_prepare(A, v, L.cand[tid]);
+            L.cand[tid].src = src;
+            batch_pos[v] = tid;
+        }
+        __syncthreads();
+        // ================= P1b: first candidate that depends on an earlier one =================
+        if (tid < nc) {
+            Cand& C = L.cand[tid];
+            bool bad = (C.flags & (CF_BIG | CF_DUP)) != 0;
+            if (!bad) {
+                for (int32_t j = 0; j < C.m; ++j) {
+                    int32_t bp = batch_pos[C.e[j].nbr];
+                    if (bp >= 0 && bp < tid) { bad = true; break; }
+                }
+            }
+            if (bad) atomicMin(&s_pmax, tid);
+        }
+        __syncthreads();
+        const int32_t Pmax = s_pmax < nc ? s_pmax : nc;
+        int32_t P = 0;
+        if (Pmax > 0) {
+            // ================= P2: RNG offsets =================
+            int dtot;
+            int dex = block_excl_scan(tid < Pmax ? L.cand[tid].ndraw : 0, L.scan, &dtot);
+            if (G.n_draws + dtot > A.rng_len) { if (tid == 0) s_status = ST_RNG_OVERFLOW; __syncthreads(); break; }
+            // ================= P3: sampling =================
+            if (tid < Pmax) {
+                L.cand[tid].draw0 = G.n_draws + dex;
+                cand_sample(A, L.cand[tid]);
             }
             __syncthreads();
-        } else {
-            wave_eliminate(A, G, L, v, e1, cp0, cp1, acnt, abase);
+            // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
+            if (tid < Pmax) {
+                Cand& C = L.cand[tid];
+                for (int32_t j = 0; j < C.m; ++j) atomicAdd(&tcount[C.e[j].nbr], 1);
+            }
+            __syncthreads();
+            if (tid < Pmax) {
+                Cand& C = L.cand[tid];
+                const bool allow_last = (done + tid + 1) + 1 < (int64_t)n;
+                for (int32_t j = 0; j < C.m; ++j) {
+                    int32_t x = C.e[j].nbr;
+                    TRes& R = ent_tres(C.e[j]);
+                    if (ld_agent(&tcount[x]) > 1) {
+                        R.flags = TF_CONTENDED; R.mv = -1; R.c = 0; R.key_after = 0;
+                        int32_t q = atomicAdd(&s_ncont, 1);
+                        if (q < CCAP) { L.cont[q].x = x; L.cont[q].i = tid; L.cont[q].j = j; }
+                        else atomicMin(&s_p, tid);     // record list full: stop the round before this candidate
+                        continue;
+                    }
+                    int mv, c; bool cx = false;
+                    int32_t k2 = cand_replay(A, C, j, use_pq ? A.key[x] : 1, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
+                    if (!use_pq) { mv = -1; cx = false; }
+                    R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c; R.flags = 0;
+                    if (cx) C.flags |= CF_COMPLEX;
+                }
+            }
+            __syncthreads();
+            // contended records: order by (x, i) with a rank sort (keys are distinct), then replay each group in order
+            const int32_t ncont = s_ncont < CCAP ? s_ncont : CCAP;
+            CRec* csorted = L.csorted;
+            for (int32_t q = tid; q < ncont; q += 256) {
+                CRec me = L.cont[q];
+                uint64_t kme = ((uint64_t)(uint32_t)me.x << 32) | (uint32_t)me.i;
+                int rank = 0;
+                for (int32_t r = 0; r < ncont; ++r) {
+                    uint64_t kr = ((uint64_t)(uint32_t)L.cont[r].x << 32) | (uint32_t)L.cont[r].i;
+                    rank += (kr < kme) ? 1 : 0;
+                }
+                csorted[rank] = me;
+            }
+            __syncthreads();
+            for (int32_t q = tid; q < ncont; q += 256) {
+                if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;   // group head only
+                int32_t x = csorted[q].x;
+                int32_t key = use_pq ? A.key[x] : 1;
+                for (int32_t r = q; r < ncont && csorted[r].x == x; ++r) {
+                    Cand& C = L.cand[csorted[r].i];
+                    const bool allow_last = (done + csorted[r].i + 1) + 1 < (int64_t)n;
+                    int mv, c; bool cx = false;
+                    int32_t k2 = cand_replay(A, C, csorted[r].j, key, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
+                    if (!use_pq) { mv = -1; cx = false; }
+                    TRes& R = ent_tres(C.e[csorted[r].j]);
+                    R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c;
+                    if (cx) atomicOr(&C.flags, CF_COMPLEX);
+                    key = k2;
+                }
+            }
+            __syncthreads();
+            // ================= P: first pre-empting / complex candidate; bound the number of moves =================
+            int mycnt = 0;
+            if (tid < Pmax) {
+                Cand& C = L.cand[tid];
+                if (C.flags & CF_COMPLEX) atomicMin(&s_p, tid);
+                bool pre = false;
+                for (int32_t j = 0; j < C.m; ++j) {
+                    TRes& R = ent_tres(C.e[j]);
+                    if (R.mv >= 0) { ++mycnt; if (pq_list_of(R.key_after, n) <= G.minlist) pre = true; }
+                }
+                if (pre) atomicMin(&s_p, tid + 1);
+                // tcount back to zero for the next round
+                for (int32_t j = 0; j < C.m; ++j) tcount[C.e[j].nbr] = 0;
+            }
+            int mtot;
+            int mex = block_excl_scan(mycnt, L.scan, &mtot);
+            if (tid < Pmax && mex + mycnt > MCAP) atomicMin(&s_p, tid);
+            __syncthreads();
+            P = s_p < Pmax ? s_p : Pmax;
         }
-        if (G.status != 0) break;
+        if (P == 0) {
+            // ================= single-vertex path for candidate 0 =================
+            ++singles;
+            const int32_t v0 = L.cand[0].v, src0 = L.cand[0].src;
+            __syncthreads();
+            if (tid < nc) batch_pos[L.cand[tid].v] = -1;
+            if (tid == 0 && use_pq) {
+                if (src0 >= 0) A.bs_cnt[b] = src0; else { A.bs_cnt[b] = 0; A.ocur[b] = (~src0) + 1; }
+                A.pqpos[v0] = -2;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                int32_t cp0 = A.colptr[v0], cp1 = A.colptr[v0 + 1];
+                int32_t acnt = A.app_cnt[v0], abase = A.app_chunk[v0];
+                if ((cp1 - cp0) + acnt > ECAP) {
+                    if (lane == 0) {
+                        ColBuf Bf = S.colbuf(G.scr_base);
+                        int rc = serial_eliminate(A, G, Bf, G.scr_cap, v0, done + 1);
+                        if (rc) G.status = rc;
+                    }
+                } else {
+                    wave_eliminate(A, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase);
+                }
+            }
+            __syncthreads();
+            if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
+            done += 1;
+            continue;
+        }
+
+        // ================= P5: commit candidates [0,P) =================
+        if (tid == 0 && use_pq) {
+            int32_t src = L.cand[P - 1].src;
+            if (src >= 0) A.bs_cnt[b] = src; else { A.bs_cnt[b] = 0; A.ocur[b] = (~src) + 1; }
+        }
+        int32_t status = 0;
+        if (tid < P) {
+            Cand& C = L.cand[tid];
+            if (use_pq) A.pqpos[C.v] = -2;
+            // targets touched by this candidate alone
+            for (int32_t j = 0; j < C.m; ++j) {
+                TRes R = ent_tres(C.e[j]);
+                if (R.flags & TF_CONTENDED) continue;
+                int32_t x = C.e[j].nbr;
+                if (R.c > 0) {
+                    int32_t a = A.app_cnt[x], chunk = A.app_chunk[x];
+                    push_into_target(A, C, j, a, chunk, &status);
+                    A.app_cnt[x] = a; A.app_chunk[x] = chunk;
+                }
+                if (use_pq && R.mv >= 0) {
+                    A.key[x] = R.key_after;
+                    int32_t q = atomicAdd(&s_nmoves, 1);
+                    if (q < MCAP) {
+                        L.mkey[q] = ((uint64_t)(uint32_t)pq_list_of(R.key_after, n) << 32) | (uint32_t)((tid << 8) | R.mv);
+                        L.mval[q] = x;
+                    }
+                }
+            }
+            // the edge to the last neighbour (or to the coarsening target) dies (:429-430 | :880-881)
+            if (C.m >= 1) A.e_val[C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin] = 0;
+        }
+        // targets shared by several candidates: one thread walks the target's records in candidate order
+        {
+            const int32_t ncont = s_ncont < CCAP ? s_ncont : CCAP;
+            const CRec* csorted = L.csorted;
+            for (int32_t q = tid; q < ncont; q += 256) {
+                if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;
+                const int32_t x = csorted[q].x;
+                if (csorted[q].i >= P) continue;
+                int32_t a = A.app_cnt[x], chunk = A.app_chunk[x];
+                const int32_t a_before = a;
+                int32_t key_final = 0, mvseq = -1;
+                for (int32_t r = q; r < ncont && csorted[r].x == x && csorted[r].i < P; ++r) {
+                    Cand& C = L.cand[csorted[r].i];
+                    push_into_target(A, C, csorted[r].j, a, chunk, &status);
+                    TRes R = ent_tres(C.e[csorted[r].j]);
+                    key_final = R.key_after;
+                    if (R.mv >= 0) mvseq = (csorted[r].i << 8) | R.mv;
+                }
+                if (a != a_before) { A.app_cnt[x] = a; A.app_chunk[x] = chunk; }
+                if (use_pq) {
+                    A.key[x] = key_final;
+                    if (mvseq >= 0) {
+                        int32_t qq = atomicAdd(&s_nmoves, 1);
+                        if (qq < MCAP) {
+                            L.mkey[qq] = ((uint64_t)(uint32_t)pq_list_of(key_final, n) << 32) | (uint32_t)mvseq;
+                            L.mval[qq] = x;
+                        }
+                    }
+                }
+            }
+        }
+        if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_POOL_OVERFLOW; __syncthreads(); break; }
+        const int32_t nmoves = s_nmoves;
+        if (nmoves > MCAP) { if (tid == 0) s_status = ST_INTERNAL; __syncthreads(); break; }
+        if (use_pq && nmoves > 0) {
+            // ---- sort the moves by (bucket, op order): bitonic, keys are distinct ----
+            int32_t npow = 1;
+            while (npow < nmoves) npow <<= 1;
+            for (int32_t q = nmoves + tid; q < npow; q += 256) { L.mkey[q] = ~0ull; L.mval[q] = -1; }
+            __syncthreads();
+            for (int32_t k = 2; k <= npow; k <<= 1) {
+                for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int32_t t = tid; t < (npow >> 1); t += 256) {
+                        int32_t lo = ((t / jj) * (jj << 1)) + (t % jj);
+                        int32_t hi = lo + jj;
+                        bool up = ((lo & k) == 0);
+                        uint64_t klo = L.mkey[lo], khi = L.mkey[hi];
+                        if ((klo > khi) == up) {
+                            L.mkey[lo] = khi; L.mkey[hi] = klo;
+                            int32_t tv = L.mval[lo]; L.mval[lo] = L.mval[hi]; L.mval[hi] = tv;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            // ---- bucket-group head index of every move (inclusive max scan) ----
+            {
+                int32_t carry = 0;
+                for (int32_t c0 = 0; c0 < nmoves; c0 += 256) {
+                    int32_t r = c0 + tid;
+                    int32_t hv = -1;
+                    if (r < nmoves) {
+                        uint32_t bk = (uint32_t)(L.mkey[r] >> 32);
+                        bool head = (r == 0) || ((uint32_t)(L.mkey[r - 1] >> 32) != bk);
+                        hv = head ? r : -1;
+                    }
+                    int32_t incl = hv;
+                    for (int off = 1; off < 64; off <<= 1) { int32_t tt = __shfl_up(incl, off); if (lane >= off) incl = max(incl, tt); }
+                    if (lane == 63) L.scan[tid >> 6] = incl;
+                    __syncthreads();
+                    int32_t pre = carry;
+                    for (int w = 0; w < (tid >> 6); ++w) pre = max(pre, L.scan[w]);
+                    incl = max(incl, pre);
+                    if (r < nmoves) L.hidx[r] = incl;
+                    int32_t nc2 = carry;
+                    for (int w = 0; w < 4; ++w) nc2 = max(nc2, L.scan[w]);
+                    carry = nc2;
+                    __syncthreads();
+                }
+            }
+            // ---- allocate new stack chunks, then write the entries ----
+            for (int32_t r = tid; r < nmoves; r += 256) {
+                int32_t lst = (int32_t)(L.mkey[r] >> 32);
+                int32_t bk = G.bucket_base + lst;
+                int32_t a = A.bs_cnt[bk] + (r - L.hidx[r]);
+                int c = bs_chunk_of(a);
+                if (c >= A.bs_alloc[bk] && a == bs_chunk_start(c)) {
+                    int32_t need = bs_chunk_cap(c);
+                    int32_t base = atomicAdd(A.bs_pool_top, need);
+                    if (base < 0 || base > A.bs_pool_cap - need) status = ST_LOG_OVERFLOW;
+                    else A.bs_dir[(int64_t)bk * BDIR + c] = base;
+                }
+            }
+            if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_LOG_OVERFLOW; __syncthreads(); break; }
+            const int32_t id0 = G.push_cnt;
+            for (int32_t r = tid; r < nmoves; r += 256) {
+                int32_t lst = (int32_t)(L.mkey[r] >> 32);
+                int32_t bk = G.bucket_base + lst;
+                int32_t a = A.bs_cnt[bk] + (r - L.hidx[r]);
+                int c = bs_chunk_of(a);
+                int32_t sl = A.bs_dir[(int64_t)bk * BDIR + c] + (a - bs_chunk_start(c));
+                int32_t v = L.mval[r];
+                A.bs_v[sl] = v; A.bs_id[sl] = id0 + r;
+                A.pqpos[v] = id0 + r;
+                L.hidx[r] = a;   // remember the position for the group tail below
+            }
+            __syncthreads();
+            for (int32_t r = tid; r < nmoves; r += 256) {
+                bool tail = (r == nmoves - 1) || ((uint32_t)(L.mkey[r + 1] >> 32) != (uint32_t)(L.mkey[r] >> 32));
+                if (tail) {
+                    int32_t lst = (int32_t)(L.mkey[r] >> 32);
+                    int32_t bk = G.bucket_base + lst;
+                    int32_t a = L.hidx[r];
+                    int c = bs_chunk_of(a);
+                    int32_t al = A.bs_alloc[bk];
+                    A.bs_cnt[bk] = a + 1;
+                    if (c + 1 > al) A.bs_alloc[bk] = c + 1;
+                }
+            }
+            if (tid == 0) {
+                int32_t lst0 = (int32_t)(L.mkey[0] >> 32);
+                if (lst0 < G.minlist) G.minlist = lst0;
+                G.push_cnt = id0 + nmoves;
+            }
+        }
+        // ---- round epilogue ----
+        if (tid < nc) batch_pos[L.cand[tid].v] = -1;
+        if (tid == 0) {
+            int64_t dr = 0;
+            for (int32_t i = 0; i < P; ++i) dr += L.cand[i].ndraw;
+            G.n_draws += dr;
+        }
+        done += P;
+        __syncthreads();
     }
     __syncthreads();
-    if (lane == 0) { G.n_elim = (int32_t)nelim; gd[g] = G; }
+    if (tid == 0) {
+        G.n_elim = (int32_t)nelim;
+        if (s_status) G.status = s_status;
+        G.pad0 = rounds; G.pad1 = singles;
+        gd[g] = G;
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -1,9 +1,10 @@
 // host_mirror.cc -- runs the SAME data-structure code the HIP kernels use
-// (rlap_amd/csrc/rlap_core.h: chunked columns, lazy bucket-stack PQ, std::sort
-// emulation, sequential elimination/output) on the CPU, so the design can be
-// checked against the oracle without a GPU.  Test-only; not part of the product.
+// (rlap_amd/csrc/rlap_core.h: chunked columns, bucket-stack PQ, std::sort
+// emulation, sequential elimination/output, batch candidates) on the CPU, so the
+// design can be checked against the oracle without a GPU.  Test-only.
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -12,6 +13,109 @@
 #include "../../rlap_amd/csrc/rlap_core.h"
 
 using namespace rlap;
+
+namespace {
+
+struct Setup {
+    int64_t n, t;
+    int32_t nnz, cap;
+    std::vector<int32_t> colptr, e_nbr, e_twin, app_cnt, app_chunk, key, pqpos, ocur, oend, orig, bs_cnt, bs_alloc, bs_dir, bs_v, bs_id;
+    std::vector<double> e_val, rng;
+    std::vector<int64_t> perm_l;
+    int32_t pool_top, bs_pool_top;
+    Arrays A;
+    GraphDesc G;
+    std::vector<SRec> rec;
+    std::vector<int32_t> i32;
+    std::vector<double> f64;
+    ColBuf B;
+
+    void build(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n_, int64_t t_, int o_v, int o_n,
+               const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots) {
+        n = n_; t = t_;
+        colptr.assign(n + 1, 0);
+        for (int64_t p = 0; p < E; ++p) if (w[p] != 0) colptr[col[p] + 1]++;
+        for (int64_t c = 0; c < n; ++c) colptr[c + 1] += colptr[c];
+        nnz = colptr[n];
+        int32_t slot_cap = nnz + pool_slots;
+        e_nbr.assign(slot_cap, 0); e_twin.assign(slot_cap, -1); e_val.assign(slot_cap, 0.0);
+        {
+            std::vector<std::pair<int64_t, int64_t>> keyed;
+            keyed.reserve(E);
+            for (int64_t p = 0; p < E; ++p) if (w[p] != 0) keyed.push_back({col[p] * n + row[p], p});
+            std::sort(keyed.begin(), keyed.end());
+            for (int32_t s = 0; s < nnz; ++s) { e_nbr[s] = (int32_t)row[keyed[s].second]; e_val[s] = w[keyed[s].second]; }
+            std::vector<int32_t> cur(colptr.begin(), colptr.end() - 1);
+            for (int64_t c = 0; c < n; ++c)
+                for (int32_t s = colptr[c]; s < colptr[c + 1]; ++s) e_twin[s] = cur[e_nbr[s]]++;
+        }
+        app_cnt.assign(n, 0); app_chunk.assign(n, -1); key.assign(n, 0); pqpos.assign(n, -1);
+        ocur.assign(2 * n + 1, 0); oend.assign(2 * n + 1, 0); orig.assign(n, 0);
+        bs_cnt.assign(2 * n + 1, 0); bs_alloc.assign(2 * n + 1, 0); bs_dir.assign((size_t)(2 * n + 1) * BDIR, -1);
+        int32_t bs_pool_cap = 4 * (int32_t)E + BCH0 * (int32_t)(2 * n + 1) + 64;
+        bs_pool_top = 0;
+        bs_v.assign(bs_pool_cap, 0); bs_id.assign(bs_pool_cap, 0);
+        for (int64_t v = 0; v < n; ++v) { key[v] = colptr[v + 1] - colptr[v]; orig[v] = (int32_t)v; }
+        std::sort(orig.begin(), orig.end(), [&](int32_t a, int32_t b) { return key[a] != key[b] ? key[a] < key[b] : a > b; });
+        for (int32_t i = 0; i < n;) {
+            int32_t j = i;
+            while (j < n && key[orig[j]] == key[orig[i]]) ++j;
+            ocur[key[orig[i]]] = i; oend[key[orig[i]]] = j;
+            i = j;
+        }
+        int64_t rng_len = (int64_t)nnz * 4 + 1024;
+        rng.resize((size_t)rng_len);
+        {
+            std::mt19937_64 g;
+            for (auto& u : rng) {
+                uint64_t raw = g();
+                double d = (double)raw * 5.42101086242752217e-20;  // 2^-64
+                if (d >= 1.0) d = 0.99999999999999989;
+                u = d;
+            }
+        }
+        perm_l.assign(n, 0);
+        if (perm) for (int64_t i = 0; i < n; ++i) perm_l[i] = perm[i];
+        pool_top = nnz;
+        A.colptr = colptr.data(); A.e_nbr = e_nbr.data(); A.e_val = e_val.data(); A.e_twin = e_twin.data();
+        A.slot_cap = slot_cap; A.pool_top = &pool_top; A.app_cnt = app_cnt.data(); A.app_chunk = app_chunk.data();
+        A.key = key.data(); A.pqpos = pqpos.data(); A.ocur = ocur.data(); A.oend = oend.data();
+        A.orig_order = orig.data();
+        A.bs_cnt = bs_cnt.data(); A.bs_alloc = bs_alloc.data(); A.bs_dir = bs_dir.data(); A.bs_v = bs_v.data(); A.bs_id = bs_id.data();
+        A.bs_pool_top = &bs_pool_top; A.bs_pool_cap = bs_pool_cap;
+        A.rng = rng.data(); A.rng_len = rng_len; A.perm = perm_l.data(); A.o_v = o_v; A.o_n = o_n; A.shuffle_seed = shuffle_seed;
+        std::memset(&G, 0, sizeof(G));
+        G.vbase = 0; G.n = (int32_t)n; G.t = t; G.bucket_base = 0;
+        cap = nnz + 8;
+        rec.resize(cap); i32.resize(11 * (size_t)cap); f64.resize(4 * (size_t)cap);
+        B.rec = rec.data();
+        int32_t* ip = i32.data();
+        B.a_slot = ip; B.a_nbr = ip + cap; B.a_twin = ip + 2 * cap; B.b_slot = ip + 3 * cap; B.b_nbr = ip + 4 * cap; B.b_twin = ip + 5 * cap;
+        B.ksel = ip + 6 * cap; B.t_key = ip + 7 * cap; B.t_mv = ip + 8 * cap; B.t_of = ip + 9 * cap;
+        B.a_val = f64.data(); B.b_val = f64.data() + cap; B.cum = f64.data() + 2 * cap; B.newv = f64.data() + 3 * cap;
+    }
+
+    // output phase (shared by both drivers)
+    int finish(int64_t nelim, int64_t npop, int64_t* order_out, double** out, int64_t* out_rows) {
+        std::vector<double> res;
+        for (int64_t q = nelim; q < n; ++q) {
+            int32_t v = (A.o_v == OV_RANDOM) ? (int32_t)perm_l[n - 1 - q] : pq_pop(A, G);
+            if (order_out) order_out[npop] = v;
+            ++npop;
+            int32_t m = serial_output(A, G, B, cap, v, nullptr, 0, true);
+            size_t r0 = res.size() / 3;
+            res.resize(res.size() + 3 * (size_t)m);
+            serial_output(A, G, B, cap, v, res.data(), (int64_t)r0, false);
+        }
+        int64_t m = (int64_t)(res.size() / 3);
+        double* o = (double*)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(3 * m, 1));
+        if (m) std::memcpy(o, res.data(), sizeof(double) * 3 * (size_t)m);
+        *out = o; *out_rows = m;
+        return 0;
+    }
+};
+
+}  // namespace
 
 extern "C" {
 
@@ -30,100 +134,242 @@ void mirror_heapsort_perm(const double* keys, int64_t n, int desc, int64_t* perm
     for (int64_t i = 0; i < n; ++i) perm_out[i] = r[i].idx;
 }
 
-// Coalesced, symmetric COO in (row[], col[], w[]) -> Schur complement rows.
-// Single graph. Returns status; *out malloc'd (m,3).
+// Coalesced, symmetric COO in (row[], col[], w[]) -> Schur complement rows,
+// sequential driver.  Single graph. Returns status; *out malloc'd (m,3).
 int mirror_approx_chol(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
                        int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots,
                        double** out, int64_t* out_rows, int64_t* order_out) {
-    // CSC by counting sort on (col,row); input assumed duplicate-free here
-    std::vector<int32_t> colptr(n + 1, 0);
-    for (int64_t p = 0; p < E; ++p) if (w[p] != 0) colptr[col[p] + 1]++;
-    for (int64_t c = 0; c < n; ++c) colptr[c + 1] += colptr[c];
-    int32_t nnz = colptr[n];
-    int32_t slot_cap = nnz + pool_slots;
-    std::vector<int32_t> e_nbr(slot_cap), e_twin(slot_cap, -1);
-    std::vector<double> e_val(slot_cap, 0.0);
-    {
-        std::vector<std::pair<int64_t, int64_t>> keyed;  // (col*n+row, p)
-        keyed.reserve(E);
-        for (int64_t p = 0; p < E; ++p) if (w[p] != 0) keyed.push_back({col[p] * n + row[p], p});
-        std::sort(keyed.begin(), keyed.end());
-        for (int32_t s = 0; s < nnz; ++s) { e_nbr[s] = (int32_t)row[keyed[s].second]; e_val[s] = w[keyed[s].second]; }
-        std::vector<int32_t> cur(colptr.begin(), colptr.end() - 1);
-        for (int64_t c = 0; c < n; ++c)
-            for (int32_t s = colptr[c]; s < colptr[c + 1]; ++s) e_twin[s] = cur[e_nbr[s]]++;
-    }
-    std::vector<int32_t> app_cnt(n, 0), app_chunk(n, -1), key(n), pqpos(n, -1);
-    std::vector<int32_t> bhead(2 * n + 1, -1), ocur(2 * n + 1, 0), oend(2 * n + 1, 0), orig(n);
-    for (int64_t v = 0; v < n; ++v) { key[v] = colptr[v + 1] - colptr[v]; orig[v] = (int32_t)v; }
-    std::sort(orig.begin(), orig.end(), [&](int32_t a, int32_t b) { return key[a] != key[b] ? key[a] < key[b] : a > b; });
-    for (int32_t i = 0; i < n;) {
-        int32_t j = i;
-        while (j < n && key[orig[j]] == key[orig[i]]) ++j;
-        ocur[key[orig[i]]] = i; oend[key[orig[i]]] = j;
-        i = j;
-    }
-    int32_t log_cap = 4 * nnz + 64;
-    std::vector<int32_t> log_v(log_cap), log_prev(log_cap);
-    int64_t rng_len = (int64_t)nnz * 4 + 1024;
-    std::vector<double> rng((size_t)rng_len);
-    {
-        std::mt19937_64 g;
-        for (auto& u : rng) {
-            uint64_t raw = g();
-            double d = (double)raw * 5.42101086242752217e-20;  // 2^-64
-            if (d >= 1.0) d = 0.99999999999999989;
-            u = d;
-        }
-    }
-    std::vector<int64_t> perm_l(n);
-    if (perm) for (int64_t i = 0; i < n; ++i) perm_l[i] = perm[i];
-    int32_t pool_top = nnz;
-    Arrays A;
-    A.colptr = colptr.data(); A.e_nbr = e_nbr.data(); A.e_val = e_val.data(); A.e_twin = e_twin.data();
-    A.slot_cap = slot_cap; A.pool_top = &pool_top; A.app_cnt = app_cnt.data(); A.app_chunk = app_chunk.data();
-    A.key = key.data(); A.pqpos = pqpos.data(); A.bhead = bhead.data(); A.ocur = ocur.data(); A.oend = oend.data();
-    A.orig_order = orig.data(); A.log_v = log_v.data(); A.log_prev = log_prev.data();
-    A.rng = rng.data(); A.rng_len = rng_len; A.perm = perm_l.data(); A.o_v = o_v; A.o_n = o_n; A.shuffle_seed = shuffle_seed;
-    GraphDesc G;
-    std::memset(&G, 0, sizeof(G));
-    G.vbase = 0; G.n = (int32_t)n; G.t = t; G.bucket_base = 0; G.log_base = 0; G.log_cap = log_cap;
-    int32_t cap = nnz + 8;
-    std::vector<SRec> rec(cap);
-    std::vector<int32_t> i32(11 * (size_t)cap);
-    std::vector<double> f64(4 * (size_t)cap);
-    ColBuf B;
-    B.rec = rec.data();
-    int32_t* ip = i32.data();
-    B.a_slot = ip; B.a_nbr = ip + cap; B.a_twin = ip + 2 * cap; B.b_slot = ip + 3 * cap; B.b_nbr = ip + 4 * cap; B.b_twin = ip + 5 * cap;
-    B.ksel = ip + 6 * cap; B.t_key = ip + 7 * cap; B.t_mv = ip + 8 * cap; B.t_of = ip + 9 * cap;
-    B.a_val = f64.data(); B.b_val = f64.data() + cap; B.cum = f64.data() + 2 * cap; B.newv = f64.data() + 3 * cap;
-
+    Setup S;
+    S.build(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots);
     int64_t nelim = std::min<int64_t>(t, n - 1);
     if (nelim < 0) nelim = 0;
     int64_t npop = 0;
     for (int64_t e1 = 1; e1 <= nelim; ++e1) {
-        int32_t v = (o_v == OV_RANDOM) ? (int32_t)perm_l[n - e1] : pq_pop(A, G);
+        int32_t v = (o_v == OV_RANDOM) ? (int32_t)S.perm_l[n - e1] : pq_pop(S.A, S.G);
         if (order_out) order_out[npop] = v;
         ++npop;
-        int rc = serial_eliminate(A, G, B, cap, v, e1);
+        int rc = serial_eliminate(S.A, S.G, S.B, S.cap, v, e1);
         if (rc) return rc;
     }
-    std::vector<double> res;
-    for (int64_t q = nelim; q < n; ++q) {
-        int32_t v = (o_v == OV_RANDOM) ? (int32_t)perm_l[n - 1 - q] : pq_pop(A, G);
-        if (order_out) order_out[npop] = v;
-        ++npop;
-        int32_t m = serial_output(A, G, B, cap, v, nullptr, 0, true);
-        size_t r0 = res.size() / 3;
-        res.resize(res.size() + 3 * (size_t)m);
-        serial_output(A, G, B, cap, v, res.data(), (int64_t)r0, false);
+    return S.finish(nelim, npop, order_out, out, out_rows);
+}
+
+// Batch driver: the round structure of the frontier kernel, executed with plain
+// loops.  Every step uses only what the parallel kernel has at that point
+// (pre-round global state + per-candidate records), so a logic error in the
+// batching rules shows up here as a mismatch with the oracle.
+// stats_out[0] = rounds, [1] = single-vertex fallbacks, [2] = contended targets.
+int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
+                             int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t Bsz,
+                             double** out, int64_t* out_rows, int64_t* order_out, int64_t* stats_out) {
+    Setup S;
+    S.build(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots);
+    const Arrays& A = S.A;
+    GraphDesc& G = S.G;
+    const bool use_pq = o_v != OV_RANDOM;
+    int64_t nelim = std::min<int64_t>(t, n - 1);
+    if (nelim < 0) nelim = 0;
+    int64_t done = 0, npop = 0, rounds = 0, singles = 0, contended_total = 0;
+    std::vector<Cand> cand((size_t)Bsz);
+    std::vector<int32_t> batch_pos((size_t)n, -1), tcount((size_t)n, 0);
+    struct CRec { int32_t x, i, j; };
+    struct Move { uint64_t key; int32_t v; };
+    while (done < nelim) {
+        ++rounds;
+        int32_t Bcur = (int32_t)std::min<int64_t>(Bsz, nelim - done);
+        // ---- P0: predict the next pops ----
+        int32_t nc = 0;
+        int32_t b = 0;
+        if (use_pq) {
+            while (true) {
+                b = G.bucket_base + G.minlist;
+                int32_t cnt = A.bs_cnt[b];
+                for (int32_t a = cnt - 1; a >= 0 && nc < Bcur; --a) {
+                    int32_t s = bs_slot(A, b, a);
+                    int32_t v = A.bs_v[s];
+                    if (A.pqpos[v] == A.bs_id[s]) { cand[nc].v = v; cand[nc].src = a; ++nc; }
+                }
+                if (nc < Bcur) {
+                    for (int32_t oc = A.ocur[b]; oc < A.oend[b] && nc < Bcur; ++oc) {
+                        int32_t v = A.orig_order[oc];
+                        if (A.pqpos[v] == -1) { cand[nc].v = v; cand[nc].src = ~oc; ++nc; }
+                    }
+                }
+                if (nc > 0) break;
+                A.bs_cnt[b] = 0; A.ocur[b] = A.oend[b];
+                G.minlist += 1;
+                if (G.minlist > 2 * G.n) return ST_INTERNAL;
+            }
+        } else {
+            for (; nc < Bcur; ++nc) { cand[nc].v = (int32_t)S.perm_l[n - (done + nc + 1)]; cand[nc].src = 0; }
+        }
+        // ---- P1: prepare (thread per candidate) ----
+        for (int32_t i = 0; i < nc; ++i) { int32_t v = cand[i].v, src = cand[i].src; cand_prepare(A, v, cand[i]); cand[i].src = src; batch_pos[v] = i; }
+        // ---- P1b: dependence; Pmax ----
+        int32_t Pmax = nc;
+        for (int32_t i = 0; i < nc; ++i) {
+            Cand& C = cand[i];
+            bool bad = (C.flags & (CF_BIG | CF_DUP)) != 0;
+            if (!bad) for (int32_t j = 0; j < C.m; ++j) { int32_t bp = batch_pos[C.e[j].nbr]; if (bp >= 0 && bp < i) { bad = true; break; } }
+            if (bad) { Pmax = std::min(Pmax, i); }
+        }
+        auto consume = [&](int32_t P) {   // candidates [0,P) leave the queue
+            if (!use_pq) return;
+            int32_t src = cand[P - 1].src;
+            if (src >= 0) A.bs_cnt[b] = src; else { A.bs_cnt[b] = 0; A.ocur[b] = (~src) + 1; }
+            for (int32_t i = 0; i < P; ++i) A.pqpos[cand[i].v] = -2;
+        };
+        auto cleanup = [&]() { for (int32_t i = 0; i < nc; ++i) batch_pos[cand[i].v] = -1; };
+        if (Pmax == 0) {
+            // candidate 0 needs the single-vertex path
+            ++singles;
+            consume(1);
+            cleanup();
+            if (order_out) order_out[npop] = cand[0].v;
+            ++npop;
+            int rc = serial_eliminate(A, G, S.B, S.cap, cand[0].v, done + 1);
+            if (rc) return rc;
+            done += 1;
+            continue;
+        }
+        // ---- P2: RNG offsets ----
+        int64_t off = G.n_draws;
+        for (int32_t i = 0; i < Pmax; ++i) { cand[i].draw0 = off; off += cand[i].ndraw; }
+        if (off > A.rng_len) return ST_RNG_OVERFLOW;
+        // ---- P3: sampling ----
+        for (int32_t i = 0; i < Pmax; ++i) cand_sample(A, cand[i]);
+        // ---- P4: PQ replay with contended targets in candidate order ----
+        for (int32_t i = 0; i < Pmax; ++i) for (int32_t j = 0; j < cand[i].m; ++j) tcount[cand[i].e[j].nbr]++;
+        std::vector<CRec> cont;
+        for (int32_t i = 0; i < Pmax; ++i) {
+            Cand& C = cand[i];
+            bool allow_last = (done + i + 1) + 1 < n;
+            for (int32_t j = 0; j < C.m; ++j) {
+                int32_t x = C.e[j].nbr;
+                TRes& R = ent_tres(C.e[j]);
+                if (tcount[x] > 1) { R.flags = TF_CONTENDED; cont.push_back({x, i, j}); continue; }
+                int mv, c; bool cx = false;
+                int32_t k2 = cand_replay(A, C, j, use_pq ? A.key[x] : 1, use_pq ? G.n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
+                if (!use_pq) { mv = -1; cx = false; }
+                R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c; R.flags = 0;
+                if (cx) C.flags |= CF_COMPLEX;
+            }
+        }
+        std::sort(cont.begin(), cont.end(), [](const CRec& p, const CRec& q) { return p.x != q.x ? p.x < q.x : p.i < q.i; });
+        contended_total += (int64_t)cont.size();
+        for (size_t q = 0; q < cont.size();) {
+            size_t r = q;
+            int32_t key = use_pq ? A.key[cont[q].x] : 1;
+            while (r < cont.size() && cont[r].x == cont[q].x) {
+                Cand& C = cand[cont[r].i];
+                bool allow_last = (done + cont[r].i + 1) + 1 < n;
+                int mv, c; bool cx = false;
+                int32_t k2 = cand_replay(A, C, cont[r].j, key, use_pq ? G.n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
+                if (!use_pq) { mv = -1; cx = false; }
+                TRes& R = ent_tres(C.e[cont[r].j]);
+                R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c;
+                if (cx) C.flags |= CF_COMPLEX;
+                key = k2;
+                ++r;
+            }
+            q = r;
+        }
+        // ---- P: first pre-emption / complex candidate ----
+        int32_t P = Pmax;
+        for (int32_t i = 0; i < Pmax; ++i) {
+            Cand& C = cand[i];
+            if (C.flags & CF_COMPLEX) { P = std::min(P, i); break; }
+            bool pre = false;
+            if (use_pq) for (int32_t j = 0; j < C.m; ++j) { TRes& R = ent_tres(C.e[j]); if (R.mv >= 0 && pq_list_of(R.key_after, G.n) <= G.minlist) pre = true; }
+            if (pre) { P = std::min(P, i + 1); break; }
+        }
+        for (int32_t i = 0; i < Pmax; ++i) for (int32_t j = 0; j < cand[i].m; ++j) tcount[cand[i].e[j].nbr] = 0;
+        if (P == 0) {
+            ++singles;
+            consume(1);
+            cleanup();
+            if (order_out) order_out[npop] = cand[0].v;
+            ++npop;
+            int rc = serial_eliminate(A, G, S.B, S.cap, cand[0].v, done + 1);
+            if (rc) return rc;
+            done += 1;
+            continue;
+        }
+        // ---- P5: commit candidates [0,P) ----
+        consume(P);
+        // column appends: per target in candidate order (contended ones share a cursor)
+        // non-contended first
+        std::vector<Move> moves;
+        for (int32_t i = 0; i < P; ++i) {
+            Cand& C = cand[i];
+            if (order_out) order_out[npop] = C.v;
+            ++npop;
+        }
+        // process per (target, candidate) in (x, i) order for contended; any order otherwise.
+        // Build list of all records of committed candidates sorted by (x, i): simple & exact.
+        std::vector<CRec> all;
+        for (int32_t i = 0; i < P; ++i) for (int32_t j = 0; j < cand[i].m; ++j) all.push_back({cand[i].e[j].nbr, i, j});
+        std::sort(all.begin(), all.end(), [](const CRec& p, const CRec& q) { return p.x != q.x ? p.x < q.x : p.i < q.i; });
+        // slots for pushes, stored back into a side table
+        std::vector<std::vector<int32_t>> pslot((size_t)P);
+        for (int32_t i = 0; i < P; ++i) pslot[i].assign(BCAP, -1);
+        for (size_t q = 0; q < all.size(); ++q) {
+            Cand& C = cand[all[q].i];
+            int32_t x = all[q].x, j = all[q].j;
+            TRes R = ent_tres(C.e[j]);
+            // pushes into column x from candidate i, in position order
+            if (A.o_v == OV_COARSEN) {
+                if (j == C.koff) for (int32_t p = 0; p < C.m; ++p) { if (p == C.koff) continue; int32_t s = col_append(A, x); if (s < 0) return ST_POOL_OVERFLOW; pslot[all[q].i][p] = s; }
+            } else {
+                for (int32_t p = 0; p < C.m - 1; ++p) if (C.ksel[p] == j) { int32_t s = col_append(A, x); if (s < 0) return ST_POOL_OVERFLOW; pslot[all[q].i][p] = s; }
+            }
+            bool last_of_x = (q + 1 == all.size()) || all[q + 1].x != x;
+            if (use_pq && last_of_x) {
+                // final state of x after the committed prefix; its last move may stem from an earlier record
+                int32_t mvseq = -1;
+                for (size_t r = q + 1; r-- > 0 && all[r].x == x;) {
+                    TRes Rr = ent_tres(cand[all[r].i].e[all[r].j]);
+                    if (Rr.mv >= 0) { mvseq = (all[r].i << 8) | Rr.mv; break; }
+                }
+                if (R.key_after != A.key[x]) A.key[x] = R.key_after;
+                if (mvseq >= 0) moves.push_back({((uint64_t)(uint32_t)pq_list_of(R.key_after, G.n) << 32) | (uint32_t)mvseq, x});
+            }
+        }
+        // rewires + kills
+        for (int32_t i = 0; i < P; ++i) {
+            Cand& C = cand[i];
+            int32_t m = C.m;
+            if (A.o_v == OV_COARSEN) {
+                if (m >= 1) {
+                    int32_t k = C.e[C.koff].nbr;
+                    for (int32_t j = 0; j < m; ++j) {
+                        if (j == C.koff) continue;
+                        int32_t s_r = C.e[j].twin, s_n = pslot[i][j];
+                        double nw = C.e[j].val;
+                        A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
+                        A.e_nbr[s_n] = C.e[j].nbr; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+                    }
+                    A.e_val[C.e[C.koff].twin] = 0;
+                }
+            } else {
+                for (int32_t j = 0; j < m - 1; ++j) {
+                    int32_t k = C.e[C.ksel[j]].nbr, s_r = C.e[j].twin, s_n = pslot[i][j];
+                    double nw = C.e[j].val;
+                    A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
+                    A.e_nbr[s_n] = C.e[j].nbr; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+                }
+                if (m >= 1) A.e_val[C.e[m - 1].twin] = 0;
+            }
+            G.n_draws += C.ndraw;
+        }
+        // PQ pushes in (bucket, op) order
+        std::sort(moves.begin(), moves.end(), [](const Move& p, const Move& q) { return p.key < q.key; });
+        for (const Move& mvv : moves) { int rc = pq_push(A, G, mvv.v, (int32_t)(mvv.key >> 32)); if (rc) return rc; }
+        cleanup();
+        done += P;
     }
-    int64_t m = (int64_t)(res.size() / 3);
-    double* o = (double*)std::malloc(sizeof(double) * (size_t)std::max<int64_t>(3 * m, 1));
-    if (m) std::memcpy(o, res.data(), sizeof(double) * 3 * (size_t)m);
-    *out = o; *out_rows = m;
-    return 0;
+    if (stats_out) { stats_out[0] = rounds; stats_out[1] = singles; stats_out[2] = contended_total; }
+    return S.finish(nelim, npop, order_out, out, out_rows);
 }
 
 void mirror_free(double* p) { std::free(p); }
