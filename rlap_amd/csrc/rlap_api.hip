@@ -52,7 +52,7 @@ struct rlap_handle_s {
     DevBuf node_ptr_d, vgraph, flags, acc, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, gcol;
     // graph state
     DevBuf e_nbr, e_val, e_twin, app_cnt, app_chunk, key, pqpos, ocur, oend, origpos, orig_order, gd_d, pool_top;
-    DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, tcount;
+    DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, tcount, prof;
     DevBuf skey0, skey1, sval0, sval1;
     DevBuf rng;
     int64_t rng_len = 0;
@@ -269,15 +269,29 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     A.perm = c.d_perm; A.o_v = c.o_v; A.o_n = c.o_n; A.shuffle_seed = c.seed;
     ElimScratch ES;
     ES.rec = h->scr_rec.as<SRec>(); ES.i32 = h->scr_i32.as<int32_t>(); ES.f64 = h->scr_f64.as<double>(); ES.cap = scr_total;
+    ES.prof = nullptr;
+    const char* prof_env = std::getenv("RLAP_PHASE_PROFILE");   // diagnostic only: per-phase clock sums of graph 0
+    if (prof_env && prof_env[0] == '1') {
+        ENSURE(h->prof, 8 * 24);
+        HIPCHK(hipMemsetAsync(h->prof.p, 0, 8 * 24, s));
+        ES.prof = h->prof.as<long long>();
+    }
 
     if (h->timing) HIPCHK(hipEventRecord(h->ev[1], s));
     // ---------------- elimination ----------------
-    hipLaunchKernelGGL(k_eliminate_batch, dim3((unsigned)G), dim3(256), 0, s, A, h->gd_d.as<GraphDesc>(), ES,
+    hipLaunchKernelGGL(k_eliminate_batch, dim3((unsigned)G), dim3(1024), 0, s, A, h->gd_d.as<GraphDesc>(), ES,
                        h->batch_pos.as<int32_t>(), h->tcount.as<int32_t>());
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
     HIPCHK(hipMemcpyAsync(gd.data(), h->gd_d.p, sizeof(GraphDesc) * G, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (ES.prof) {
+        long long pr[24];
+        HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
+        const char* names[15] = {"P0 select", "P1c4 permute", "P1b depend", "P2+P3 offsets+sample", "P4 replay", "single path", "P5b slots+contended", "moves sort", "pushes", "P1ab meta+loads", "P5a loads+scan+bump", "P5c rewire stores", "P1c1 rank", "P1c2 write", "P1c3 order-index"};
+        std::fprintf(stderr, "[rlap phase profile] rounds=%lld singles=%lld (100 MHz ticks)\n", pr[22], pr[23]);
+        for (int k = 0; k < 15; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
+    }
     for (int64_t g = 0; g < G; ++g) {
         if (gd[g].status) {
             int stt = gd[g].status;
@@ -390,7 +404,7 @@ int rlap_destroy(rlap_handle h) {
     if (!h) return RLAP_OK;
     DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->flags, &h->acc, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
                       &h->deg, &h->colptr, &h->slot_col, &h->gcol, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
-                      &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->tcount, &h->gd_d, &h->pool_top, &h->skey0,
+                      &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->tcount, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
                       &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters};
     for (DevBuf* b : bufs) b->release();

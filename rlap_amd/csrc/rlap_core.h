@@ -202,6 +202,41 @@ RLAP_HD void gs_introsort_loop(P a, int n, Less less) {
     }
 }
 
+// Same loop for n <= 32: after a partition at most one side can still exceed the
+// threshold of 16, so no stack is needed (nothing lands in scratch memory).
+template <class T, class Less, class P>
+RLAP_HD void gs_introsort_loop_small(P a, int n, Less less) {
+    if (n <= 16) return;
+    int depth = 0;
+    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth;
+    depth *= 2;
+    int first = 0, last = n;
+    while (last - first > 16) {
+        if (depth == 0) { gs_heap_sort<T>(a, first, last, less); break; }
+        --depth;
+        int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+        int pick;
+        if (less(a[ia], a[ib])) {
+            if (less(a[ib], a[ic])) pick = ib;
+            else if (less(a[ia], a[ic])) pick = ic;
+            else pick = ia;
+        } else if (less(a[ia], a[ic])) pick = ia;
+        else if (less(a[ib], a[ic])) pick = ic;
+        else pick = ib;
+        { T t = a[first]; a[first] = a[pick]; a[pick] = t; }
+        T pv = a[first];
+        int f = first + 1, l = last;
+        while (true) {
+            while (less(a[f], pv)) ++f;
+            --l;
+            while (less(pv, a[l])) --l;
+            if (!(f < l)) break;
+            T t = a[f]; a[f] = a[l]; a[l] = t;
+            ++f;
+        }
+        if (last - f > 16) first = f; else last = f;   // the other side is <= 16 and needs no more partitioning
+    }
+}
 // __final_insertion_sort == stable insertion sort of the whole range (the
 // unguarded part never runs past the sentinel left by the partitions).
 template <class T, class Less, class P>
@@ -212,6 +247,13 @@ RLAP_HD void gs_insertion_sort(P a, int n, Less less) {
         while (j >= 0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
         a[j + 1] = v;
     }
+}
+
+template <class T, class Less, class P>
+RLAP_HD void gs_std_sort_small(P a, int n, Less less) {   // n <= 32
+    if (n < 2) return;
+    gs_introsort_loop_small<T>(a, n, less);
+    gs_insertion_sort<T>(a, n, less);
 }
 
 template <class T, class Less, class P>
@@ -591,7 +633,7 @@ struct Ent {
     int32_t nbr;
     int32_t twin;
 };
-enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8 };
+enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8, CF_TIE = 16, CF_NEQ = 32 };
 enum { TF_CONTENDED = 1 };
 
 struct Cand {
@@ -601,10 +643,14 @@ struct Cand {
     int32_t m;        // live (= distinct) neighbours
     int32_t flags;
     int32_t src;      // >= 0: bucket-stack index it was read from; < 0: ~(index into orig_order)
-    int64_t draw0;    // first uniform
     int32_t ndraw;
     int32_t koff;     // coarsen: chosen position
-};
+    int32_t cp1;      // colptr[v+1]
+    int32_t acnt;     // appended entries
+    int32_t ext;      // slots to read (appended + CSR), dead ones included
+    int32_t cb[3];    // bases of the appended chunks 0..2
+    int64_t draw0;    // first uniform
+};   // 856 B: an even, non-power-of-two word stride keeps per-candidate LDS accesses ~conflict free
 
 RLAP_HD TRes& ent_tres(Ent& e) { return e.res; }
 
@@ -613,49 +659,73 @@ struct EntLessVal { RLAP_HD bool operator()(const Ent& x, const Ent& y) const { 
 struct EntGreaterVal { RLAP_HD bool operator()(const Ent& x, const Ent& y) const { return x.val > y.val; } };
 struct EntLessAux { RLAP_HD bool operator()(const Ent& x, const Ent& y) const { return x.aux < y.aux; } };
 
-// gather (reference traversal order) -> sort by id -> (no multi-edges allowed) -> order by o_n
-RLAP_HD void cand_prepare(const Arrays& A, int32_t v, Cand& C) {
+// (key, index) view over a candidate's Ent::aux / ksel[] arrays, so the o_n order can
+// be found by moving 9 bytes per element instead of whole entries.  The permutation
+// std::sort produces depends on the comparison outcomes only, not on the payload.
+struct KI { double k; uint8_t idx; };
+struct KIRef {
+    Ent* e; uint8_t* ix; int i;
+    RLAP_HD operator KI() const { KI v; v.k = e[i].aux; v.idx = ix[i]; return v; }
+    RLAP_HD KIRef& operator=(const KI& v) { e[i].aux = v.k; ix[i] = v.idx; return *this; }
+    RLAP_HD KIRef& operator=(const KIRef& o) { KI v = o; e[i].aux = v.k; ix[i] = v.idx; return *this; }
+};
+struct KIArr {
+    Ent* e; uint8_t* ix;
+    RLAP_HD KIRef operator[](int i) const { KIRef r; r.e = e; r.ix = ix; r.i = i; return r; }
+};
+struct KILess { RLAP_HD bool operator()(const KI& x, const KI& y) const { return x.k < y.k; } };
+struct KIGreater { RLAP_HD bool operator()(const KI& x, const KI& y) const { return x.k > y.k; } };
+
+// o_n order of a candidate whose entries are already sorted by id and carry the sort key
+// in aux (weight, or the keyed-order key): leaves the source index of position j in ksel[j].
+RLAP_HD void cand_order_index(const Arrays& A, Cand& C) {
+    const int32_t m = C.m;
+    for (int32_t j = 0; j < m; ++j) C.ksel[j] = (uint8_t)j;
+    KIArr arr; arr.e = C.e; arr.ix = C.ksel;
+    if (A.o_n == ON_DESC && A.o_v != OV_COARSEN) gs_std_sort_small<KI>(arr, m, KIGreater());
+    else gs_std_sort_small<KI>(arr, m, KILess());
+    C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
+}
+
+// Candidate preparation in three steps so the loads can be spread over all
+// threads: cand_meta (one per candidate), cand_load (one per slot), cand_finish.
+RLAP_HD void cand_meta(const Arrays& A, int32_t v, Cand& C) {
     C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0;
-    int32_t len = 0;
-    bool big = false;
-    int32_t a = A.app_cnt[v];
-    if (a > 0) {
+    int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
+    int32_t acnt = A.app_cnt[v];
+    C.cp1 = cp1; C.acnt = acnt; C.ext = (cp1 - cp0) + acnt;
+    if (C.ext > BCAP) { C.flags = CF_BIG; C.ext = 0; return; }
+    if (acnt > 0) {
+        int ct = chunk_of(acnt - 1);            // <= 2 because acnt <= BCAP
         int32_t base = A.app_chunk[v];
-        int c = chunk_of(a - 1);
-        int32_t idx = a - 1;
-        while (idx >= 0 && !big) {
-            int32_t cs = chunk_start(c);
-            for (int32_t t = idx; t >= cs; --t) {
-                int32_t s = base + 1 + (t - cs);
-                double val = A.e_val[s];
-                if (val > 0) {
-                    if (len >= BCAP) { big = true; break; }
-                    C.e[len].val = val; C.e[len].nbr = A.e_nbr[s]; C.e[len].twin = A.e_twin[s]; C.e[len].aux = 0;
-                    ++len;
-                }
-            }
-            idx = cs - 1;
-            base = A.e_nbr[base];
-            --c;
-        }
+        for (int c = ct; c >= 0; --c) { C.cb[c] = base; if (c > 0) base = A.e_nbr[base]; }
     }
-    if (!big) {
-        int32_t cp0 = A.colptr[v];
-        for (int32_t s = A.colptr[v + 1] - 1; s >= cp0; --s) {
-            double val = A.e_val[s];
-            if (val > 0) {
-                if (len >= BCAP) { big = true; break; }
-                C.e[len].val = val; C.e[len].nbr = A.e_nbr[s]; C.e[len].twin = A.e_twin[s]; C.e[len].aux = 0;
-                ++len;
-            }
-        }
+}
+// traversal position e of the column (:248-271): appended entries newest first, then the CSR segment backwards
+RLAP_HD int32_t cand_slot(const Cand& C, int32_t e) {
+    if (e < C.acnt) {
+        int32_t a = C.acnt - 1 - e;
+        int c = chunk_of(a);
+        return C.cb[c] + 1 + (a - chunk_start(c));
     }
-    if (big) { C.flags = CF_BIG; return; }
+    return C.cp1 - 1 - (e - C.acnt);
+}
+RLAP_HD void cand_load(const Arrays& A, Cand& C, int32_t e) {
+    int32_t s = cand_slot(C, e);
+    C.e[e].val = A.e_val[s]; C.e[e].nbr = A.e_nbr[s]; C.e[e].twin = A.e_twin[s]; C.e[e].aux = 0;
+}
+// drop dead entries -> sort by id (:275) -> multi-edges go to the single-vertex path -> order by o_n (:295-307)
+RLAP_HD void cand_finish(const Arrays& A, Cand& C) {
+    if (C.flags & CF_BIG) return;
+    int32_t len = 0;
+    for (int32_t e = 0; e < C.ext; ++e) {
+        if (C.e[e].val > 0) { if (len != e) C.e[len] = C.e[e]; ++len; }
+    }
     C.m = len;
     gs_std_sort<Ent>(C.e, len, EntLessNbr());
     for (int32_t i = 1; i < len; ++i) if (C.e[i].nbr == C.e[i - 1].nbr) { C.flags = CF_DUP; return; }
     if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
-        uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
+        uint64_t kb = keyed_order_base(A.shuffle_seed, C.v, 0);
         for (int32_t i = 0; i < len; ++i) C.e[i].aux = keyed_order_dkey(kb, C.e[i].nbr);
         gs_std_sort<Ent>(C.e, len, EntLessAux());
     } else if (A.o_n == ON_ASC) {
@@ -664,6 +734,11 @@ RLAP_HD void cand_prepare(const Arrays& A, int32_t v, Cand& C) {
         gs_std_sort<Ent>(C.e, len, EntGreaterVal());
     }
     C.ndraw = (A.o_v == OV_COARSEN) ? (len >= 1 ? 1 : 0) : (len > 1 ? len - 1 : 0);
+}
+RLAP_HD void cand_prepare(const Arrays& A, int32_t v, Cand& C) {
+    cand_meta(A, v, C);
+    for (int32_t e = 0; e < C.ext; ++e) cand_load(A, C, e);
+    cand_finish(A, C);
 }
 
 RLAP_HD int32_t ent_upper_index(const Ent* e, int32_t m, double r) {  // first a with cum[a] > r, else m-1
@@ -675,14 +750,13 @@ RLAP_HD int32_t ent_upper_index(const Ent* e, int32_t m, double r) {  // first a
     return lo < m ? lo : m - 1;
 }
 
-// cumulative weights, the f/colScale/wdeg recurrences and the sampled targets
-// (:366-417 | :856-897).  Leaves the new edge weight of position j in e[j].val.
-RLAP_HD void cand_sample(const Arrays& A, Cand& C) {
+// cumulative weights (:366-373); coarsen also draws its single target and the
+// collapsed weights here (:867-897)
+RLAP_HD void cand_cumsum(const Arrays& A, Cand& C) {
     const int32_t m = C.m;
     double csum = 0;
     for (int32_t j = 0; j < m; ++j) { csum += C.e[j].val; C.e[j].aux = csum; }
-    if (A.o_v == OV_COARSEN) {
-        if (m < 1) return;
+    if (A.o_v == OV_COARSEN && m >= 1) {
         double u = A.rng[C.draw0];
         double r = u * csum;
         int32_t koff = ent_upper_index(C.e, m, r);
@@ -694,15 +768,23 @@ RLAP_HD void cand_sample(const Arrays& A, Cand& C) {
             C.e[j].val = (wk * w) / (wk + w);
             C.ksel[j] = (uint8_t)koff;
         }
-        return;
     }
-    for (int32_t j = 0; j < m - 1; ++j) {
-        double u = A.rng[C.draw0 + j];
-        double cj = C.e[j].aux;
-        double r = u * (csum - cj) + cj;
-        C.ksel[j] = (uint8_t)ent_upper_index(C.e, m, r);
-    }
-    double wdeg = csum, colScale = 1;
+}
+// sampled target of position j < m-1 (:385-394); degree/random only
+RLAP_HD void cand_pick(const Arrays& A, Cand& C, int32_t j) {
+    const int32_t m = C.m;
+    double csum = C.e[m - 1].aux;
+    double u = A.rng[C.draw0 + j];
+    double cj = C.e[j].aux;
+    double r = u * (csum - cj) + cj;
+    C.ksel[j] = (uint8_t)ent_upper_index(C.e, m, r);
+}
+// the f / colScale / wdeg recurrences (:374-417): leaves the new edge weight of position j in e[j].val
+RLAP_HD void cand_recur(const Arrays& A, Cand& C) {
+    if (A.o_v == OV_COARSEN) return;
+    const int32_t m = C.m;
+    if (m < 1) return;
+    double wdeg = C.e[m - 1].aux, colScale = 1;
     for (int32_t j = 0; j < m - 1; ++j) {
         double w = C.e[j].val * colScale;
         double f = w / wdeg;
@@ -711,6 +793,11 @@ RLAP_HD void cand_sample(const Arrays& A, Cand& C) {
         colScale = colScale * omf;
         wdeg = wdeg * omf * omf;
     }
+}
+RLAP_HD void cand_sample(const Arrays& A, Cand& C) {
+    cand_cumsum(A, C);
+    if (A.o_v != OV_COARSEN) for (int32_t j = 0; j < C.m - 1; ++j) cand_pick(A, C, j);
+    cand_recur(A, C);
 }
 
 // Net PQ effect of candidate C on its target at position j, starting from key0

@@ -17,6 +17,7 @@ struct ElimScratch {
     int32_t* i32;   // 10 arrays of `cap` ints, interleaved per array
     double* f64;    // 4 arrays of `cap` doubles
     int64_t cap;    // total entries over all graphs
+    long long* prof; // optional diagnostic build only: per-phase cycle sums of graph 0 (nullptr in production)
     __host__ __device__ ColBuf colbuf(int64_t base) const {
         ColBuf B;
         B.rec = rec + base;

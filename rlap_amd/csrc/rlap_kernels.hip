@@ -223,7 +223,7 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const int32_
 }
 
 // ---------------------------------------------------------------------------
-// K5-K8: elimination.  One 256-thread workgroup per graph runs rounds of the batch
+// K5-K8: elimination.  One 1024-thread workgroup per graph runs rounds of the batch
 // ("frontier") scheme; vertices it cannot take (long columns, multi-edges, keys
 // beyond n) go through the single-vertex wave path or the sequential fallback.
 // ---------------------------------------------------------------------------
@@ -284,7 +284,7 @@ __device__ __forceinline__ int32_t alloc_in_column(const Arrays& A, int32_t& a, 
 }
 
 // Single-vertex path, executed by ONE wave (columns up to ECAP entries, multi-edges, any key range).
-__device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
+__device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
                                int32_t acnt, int32_t abase) {
     const int lane = lane_id();
     const bool use_pq = A.o_v != OV_RANDOM;
@@ -577,8 +577,12 @@ __device__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_
 // ---------------------------------------------------------------------------
 // Batch kernel
 // ---------------------------------------------------------------------------
+constexpr int NT = 1024;      // threads per workgroup of the batch kernel (measured faster than 512 despite tighter registers)
+constexpr int NWAVE = NT / 64;
 constexpr int BATCH = 128;    // candidates per round
-constexpr int MCAP = 2048;    // PQ moves per round (sorted in LDS)
+constexpr int BCAP_ = 32;
+constexpr int PASSES = BATCH * BCAP_ / NT;   // (candidate, slot) pairs per thread
+constexpr int MCAP = NT;      // PQ moves per round: one per thread, sorted in registers + LDS
 constexpr int CCAP = 512;     // contended (target, candidate) records per round
 
 struct CRec { int32_t x, i, j; };
@@ -588,9 +592,10 @@ struct BatchLds {
     uint64_t mkey[MCAP];
     int32_t mval[MCAP];
     int32_t hidx[MCAP];
+    int32_t pslot[BATCH * BCAP_];   // slot of the entry position p of candidate i appends (commit phase)
     CRec cont[CCAP];
     CRec csorted[CCAP];
-    int32_t scan[260];
+    int32_t scan[NWAVE + 8];
 };
 
 union ElimShared {
@@ -598,7 +603,7 @@ union ElimShared {
     ElimLds e;
 };
 
-// exclusive block scan over 256 threads (4 waves); returns exclusive prefix, *total = sum
+// exclusive block scan over NT threads; returns exclusive prefix, *total = sum
 __device__ __forceinline__ int block_excl_scan(int val, int* scratch, int* total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int incl = val;
@@ -606,7 +611,7 @@ __device__ __forceinline__ int block_excl_scan(int val, int* scratch, int* total
     if (lane == 63) scratch[wave] = incl;
     __syncthreads();
     int base = 0, tot = 0;
-    for (int w = 0; w < 4; ++w) { int sw = scratch[w]; if (w < wave) base += sw; tot += sw; }
+    for (int w = 0; w < NWAVE; ++w) { int sw = scratch[w]; if (w < wave) base += sw; tot += sw; }
     __syncthreads();
     *total = tot;
     return base + incl - val;
@@ -646,16 +651,43 @@ __device__ __forceinline__ void push_into_target(const Arrays& A, const Cand& C,
     }
 }
 
-__global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __restrict__ gd, ElimScratch S,
+// slots for all pushes of candidate C into the column of its target at position j (position order)
+__device__ __forceinline__ void slots_into_target(const Arrays& A, const Cand& C, int32_t j, int32_t& a, int32_t& chunk, int32_t* status, int32_t* pslot_row) {
+    const bool co = A.o_v == OV_COARSEN;
+    if (co && j != C.koff) return;
+    const int32_t plast = co ? C.m : C.m - 1;
+    for (int32_t p = 0; p < plast; ++p) {
+        if (co ? (p == C.koff) : (C.ksel[p] != j)) continue;
+        pslot_row[p] = alloc_in_column(A, a, chunk, status);
+        if (*status) return;
+    }
+}
+
+__device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G, const ElimScratch& S, int32_t v0, int64_t e1) {
+    ColBuf Bf = S.colbuf(G.scr_base);
+    int rc = serial_eliminate(A, G, Bf, G.scr_cap, v0, e1);
+    if (rc) G.status = rc;
+}
+
+__global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __restrict__ gd, ElimScratch S,
                                                          int32_t* __restrict__ batch_pos, int32_t* __restrict__ tcount) {
     __shared__ ElimShared sh;
     __shared__ GraphDesc G;
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status;
+    __shared__ uint8_t s_eqperm[16][32];   // std::sort's permutation of n = 17..32 all-equal keys
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     if (tid == 0) { G = gd[g]; s_status = 0; }
+    if (tid < 16) {
+        Cand& C = L.cand[tid];
+        const int nn = 17 + tid;
+        for (int q = 0; q < nn; ++q) { C.e[q].aux = 1.0; C.ksel[q] = (uint8_t)q; }
+        KIArr arr; arr.e = C.e; arr.ix = C.ksel;
+        gs_std_sort_small<KI>(arr, nn, KILess());
+        for (int q = 0; q < 32; ++q) s_eqperm[tid][q] = q < nn ? C.ksel[q] : (uint8_t)q;
+    }
     __syncthreads();
     const int32_t n = G.n;
     const bool use_pq = A.o_v != OV_RANDOM;
@@ -663,6 +695,10 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
     if (nelim < 0) nelim = 0;
     int64_t done = 0;
     int32_t rounds = 0, singles = 0;
+    long long t_prev = 0;
+    __shared__ long long s_prof[24];   // diagnostic build only (S.prof != nullptr)
+#define PHASE_STAMP(k) do { if (S.prof && tid == 0 && g == 0) { long long _t = wall_clock64(); s_prof[k] += _t - t_prev; t_prev = _t; } } while (0)
+    if (S.prof && tid == 0 && g == 0) { for (int q = 0; q < 24; ++q) s_prof[q] = 0; t_prev = wall_clock64(); }
 
     while (done < nelim) {
         ++rounds;
@@ -693,7 +729,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                     if (valid && base + r < Bcur) { L.cand[base + r].v = v; L.cand[base + r].src = a; }
                     if (tid == 0) s_nc = (base + tot < Bcur) ? base + tot : Bcur;
                     __syncthreads();
-                    top -= 256;
+                    top -= NT;
                 }
                 // never-moved members, descending id
                 int32_t oc0 = A.ocur[b];
@@ -710,7 +746,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                     if (valid && base + r < Bcur) { L.cand[base + r].v = v; L.cand[base + r].src = ~oc; }
                     if (tid == 0) s_nc = (base + tot < Bcur) ? base + tot : Bcur;
                     __syncthreads();
-                    oc0 += 256;
+                    oc0 += NT;
                 }
                 if (s_nc > 0) break;
                 __syncthreads();
@@ -729,30 +765,184 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
             __syncthreads();
         }
         const int32_t nc = s_nc;
+        PHASE_STAMP(0);
 
-        // ================= P1: prepare (one thread per candidate) =================
+        // ================= P1: prepare =================
+        // (a) per candidate: column extent + chunk bases; (b) per slot: the loads; (c) per candidate: filter + sorts
         if (tid < nc) {
             int32_t v = L.cand[tid].v, src = L.cand[tid].src;
-            cand_prepare(A, v, L.cand[tid]);
+            cand_meta(A, v, L.cand[tid]);
             L.cand[tid].src = src;
             batch_pos[v] = tid;
         }
         __syncthreads();
-        // ================= P1b: first candidate that depends on an earlier one =================
-        if (tid < nc) {
-            Cand& C = L.cand[tid];
-            bool bad = (C.flags & (CF_BIG | CF_DUP)) != 0;
-            if (!bad) {
-                for (int32_t j = 0; j < C.m; ++j) {
-                    int32_t bp = batch_pos[C.e[j].nbr];
-                    if (bp >= 0 && bp < tid) { bad = true; break; }
+        {
+            // BATCH*BCAP = 4*NT slots: issue every load before the first LDS store
+            static_assert(BATCH * BCAP == PASSES * NT && BCAP == BCAP_, "slot loops are unrolled for PASSES passes");
+            double lv[PASSES]; int32_t ln[PASSES], lt[PASSES]; bool la[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t idx = k * NT + tid;
+                const int32_t i = idx / BCAP, e = idx % BCAP;
+                la[k] = (i < nc) && (e < L.cand[i].ext);
+                lv[k] = 0; ln[k] = 0; lt[k] = 0;
+                if (la[k]) {
+                    int32_t sl = cand_slot(L.cand[i], e);
+                    lv[k] = A.e_val[sl]; ln[k] = A.e_nbr[sl]; lt[k] = A.e_twin[sl];
                 }
             }
-            if (bad) atomicMin(&s_pmax, tid);
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                if (la[k]) {
+                    const int32_t idx = k * NT + tid;
+                    Ent& E = L.cand[idx / BCAP].e[idx % BCAP];
+                    E.val = lv[k]; E.nbr = ln[k];
+                }
+            }
+            __syncthreads();
+            PHASE_STAMP(9);
+            // rank of every live entry among its column's live entries by id: with distinct ids the
+            // sorted order is unique, so no std::sort emulation is needed (equal ids -> single-vertex path).
+            // One half-wave = one candidate.  A column without appended entries whose CSR segment is still
+            // sorted is read in descending id, so its rank is a popcount of the live mask; others loop.
+            int32_t rk[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t idx = k * NT + tid;
+                const int32_t i = idx / BCAP, e = idx % BCAP;
+                const bool live = la[k] && lv[k] > 0;
+                const uint32_t half = (uint32_t)(__ballot(live) >> (lane & 32));
+                // in-place twin rewrites (:404-406) can leave a CSR segment unsorted: the shortcut needs
+                // every slot (live or dead) strictly above its successor
+                const int32_t nxt = __shfl_down(ln[k], 1);
+                const bool unsorted = la[k] && (i < nc) && (e + 1 < L.cand[i].ext) && !(ln[k] > nxt);
+                const uint32_t hbad = (uint32_t)(__ballot(unsorted) >> (lane & 32));
+                rk[k] = -1;
+                if (i < nc && L.cand[i].ext > 0) {
+                    Cand& C = L.cand[i];
+                    if (C.acnt == 0 && hbad == 0) {
+                        if (live) rk[k] = __popc(half & ~((2u << e) - 1u));
+                        if (e == 0) C.m = __popc(half);
+                    } else if (live) {
+                        const int32_t ext = C.ext, me = ln[k];
+                        int32_t r = 0, nlive = 0;
+                        bool dup = false;
+                        for (int32_t q = 0; q < ext; ++q) {
+                            bool lq = C.e[q].val > 0;
+                            int32_t nq = C.e[q].nbr;
+                            nlive += lq ? 1 : 0;
+                            r += (lq && nq < me) ? 1 : 0;
+                            dup |= (lq && nq == me && q != e);
+                        }
+                        rk[k] = r;
+                        if (dup) atomicOr(&C.flags, CF_DUP);
+                        if (r == 0) C.m = nlive;
+                    }
+                }
+            }
+            __syncthreads();
+            PHASE_STAMP(12);
+            const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                if (rk[k] >= 0) {
+                    const int32_t idx = k * NT + tid;
+                    Cand& C = L.cand[idx / BCAP];
+                    Ent& E = C.e[rk[k]];
+                    E.val = lv[k]; E.nbr = ln[k]; E.twin = lt[k];
+                    E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v, 0), ln[k]) : lv[k];
+                }
+            }
+            __syncthreads();
+            // o_n order with std::sort semantics under ties.  All-equal keys (unit weights): identity for
+            // m <= 16, a precomputed permutation above.  Otherwise a stable rank is exact for m <= 16
+            // (pure insertion sort) and whenever the keys are distinct; the rest is emulated by one thread.
+            const bool desc = (A.o_n == ON_DESC) && !keyed;
+            int32_t r2[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                r2[k] = -1;
+                const int32_t idx = k * NT + tid;
+                const int32_t i = idx / BCAP, j = idx % BCAP;
+                const bool valid = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP)) && (j < L.cand[i].m);
+                double kme = 0, k0 = 0;
+                if (valid) { kme = L.cand[i].e[j].aux; k0 = L.cand[i].e[0].aux; }
+                const uint32_t hdiff = (uint32_t)(__ballot(valid && kme != k0) >> (lane & 32));
+                if (valid) {
+                    Cand& C = L.cand[i];
+                    const int32_t m = C.m;
+                    if (hdiff == 0) {
+                        C.ksel[j] = (m <= 16) ? (uint8_t)j : s_eqperm[m - 17][j];
+                    } else {
+                        int32_t r = 0; bool tie = false;
+                        for (int32_t q = 0; q < m; ++q) {
+                            const double kq = C.e[q].aux;
+                            const bool eq = (kq == kme);
+                            const bool before = desc ? (kq > kme) : (kq < kme);
+                            r += (before || (eq && q < j)) ? 1 : 0;
+                            tie |= (eq && q != j);
+                        }
+                        r2[k] = r;
+                        if (tie) atomicOr(&C.flags, CF_TIE);
+                        if (j == 0) atomicOr(&C.flags, CF_NEQ);
+                    }
+                }
+            }
+            __syncthreads();
+            PHASE_STAMP(13);
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                if (r2[k] >= 0) {
+                    const int32_t idx = k * NT + tid;
+                    Cand& C = L.cand[idx / BCAP];
+                    if (C.m <= 16 || !(C.flags & CF_TIE)) C.ksel[r2[k]] = (uint8_t)(idx % BCAP);
+                }
+            }
+            if (tid < nc) {
+                Cand& C = L.cand[tid];
+                if (!(C.flags & (CF_BIG | CF_DUP))) {
+                    const int32_t m = C.m;
+                    if (m > 16 && (C.flags & CF_TIE) && (C.flags & CF_NEQ)) cand_order_index(A, C);
+                    C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
+                }
+            }
+            __syncthreads();
+            PHASE_STAMP(14);
+            // apply the permutation: every position fetches its source entry, then all store
+            double pv[PASSES]; int32_t pn[PASSES], pt[PASSES]; bool pa[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t idx = k * NT + tid;
+                const int32_t i = idx / BCAP, j = idx % BCAP;
+                pa[k] = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP)) && (j < L.cand[i].m);
+                pv[k] = 0; pn[k] = 0; pt[k] = 0;
+                if (pa[k]) { const Ent& Sx = L.cand[i].e[L.cand[i].ksel[j]]; pv[k] = Sx.val; pn[k] = Sx.nbr; pt[k] = Sx.twin; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                if (pa[k]) {
+                    const int32_t idx = k * NT + tid;
+                    Ent& E = L.cand[idx / BCAP].e[idx % BCAP];
+                    E.val = pv[k]; E.nbr = pn[k]; E.twin = pt[k]; E.aux = 0;
+                }
+            }
+        }
+        __syncthreads();
+        PHASE_STAMP(1);
+        // ================= P1b: first candidate that depends on an earlier one =================
+        if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);
+        for (int32_t idx = tid; idx < nc * BCAP; idx += NT) {
+            const int32_t i = idx / BCAP, j = idx % BCAP;
+            if (j < L.cand[i].m) {
+                int32_t bp = batch_pos[L.cand[i].e[j].nbr];
+                if (bp >= 0 && bp < i) atomicMin(&s_pmax, i);
+            }
         }
         __syncthreads();
         const int32_t Pmax = s_pmax < nc ? s_pmax : nc;
         int32_t P = 0;
+        PHASE_STAMP(2);
         if (Pmax > 0) {
             // ================= P2: RNG offsets =================
             int dtot;
@@ -761,40 +951,51 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
             // ================= P3: sampling =================
             if (tid < Pmax) {
                 L.cand[tid].draw0 = G.n_draws + dex;
-                cand_sample(A, L.cand[tid]);
+                cand_cumsum(A, L.cand[tid]);
             }
             __syncthreads();
-            // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
-            if (tid < Pmax) {
-                Cand& C = L.cand[tid];
-                for (int32_t j = 0; j < C.m; ++j) atomicAdd(&tcount[C.e[j].nbr], 1);
-            }
-            __syncthreads();
-            if (tid < Pmax) {
-                Cand& C = L.cand[tid];
-                const bool allow_last = (done + tid + 1) + 1 < (int64_t)n;
-                for (int32_t j = 0; j < C.m; ++j) {
-                    int32_t x = C.e[j].nbr;
-                    TRes& R = ent_tres(C.e[j]);
-                    if (ld_agent(&tcount[x]) > 1) {
-                        R.flags = TF_CONTENDED; R.mv = -1; R.c = 0; R.key_after = 0;
-                        int32_t q = atomicAdd(&s_ncont, 1);
-                        if (q < CCAP) { L.cont[q].x = x; L.cont[q].i = tid; L.cont[q].j = j; }
-                        else atomicMin(&s_p, tid);     // record list full: stop the round before this candidate
-                        continue;
-                    }
-                    int mv, c; bool cx = false;
-                    int32_t k2 = cand_replay(A, C, j, use_pq ? A.key[x] : 1, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
-                    if (!use_pq) { mv = -1; cx = false; }
-                    R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c; R.flags = 0;
-                    if (cx) C.flags |= CF_COMPLEX;
+            if (A.o_v != OV_COARSEN) {
+                for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
+                    const int32_t i = idx / BCAP, j = idx % BCAP;
+                    if (j < L.cand[i].m - 1) cand_pick(A, L.cand[i], j);
                 }
+                if (tid < Pmax) cand_recur(A, L.cand[tid]);   // touches e[].val only
+            }
+            __syncthreads();
+            PHASE_STAMP(3);
+            // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
+            for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
+                const int32_t i = idx / BCAP, j = idx % BCAP;
+                if (j < L.cand[i].m) atomicAdd(&tcount[L.cand[i].e[j].nbr], 1);
+            }
+            __syncthreads();
+            for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
+                const int32_t i = idx / BCAP, j = idx % BCAP;
+                Cand& C = L.cand[i];
+                if (j >= C.m) continue;
+                const int32_t x = C.e[j].nbr;
+                const int32_t tc = ld_agent(&tcount[x]);
+                const int32_t key0 = use_pq ? A.key[x] : 1;
+                TRes& R = ent_tres(C.e[j]);
+                if (tc > 1) {
+                    R.flags = TF_CONTENDED; R.mv = -1; R.c = 0; R.key_after = 0;
+                    int32_t q = atomicAdd(&s_ncont, 1);
+                    if (q < CCAP) { L.cont[q].x = x; L.cont[q].i = i; L.cont[q].j = j; }
+                    else atomicMin(&s_p, i);     // record list full: stop the round before this candidate
+                    continue;
+                }
+                const bool allow_last = (done + i + 1) + 1 < (int64_t)n;
+                int mv, c; bool cx = false;
+                int32_t k2 = cand_replay(A, C, j, key0, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
+                if (!use_pq) { mv = -1; cx = false; }
+                R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c; R.flags = 0;
+                if (cx) atomicOr(&C.flags, CF_COMPLEX);
             }
             __syncthreads();
             // contended records: order by (x, i) with a rank sort (keys are distinct), then replay each group in order
             const int32_t ncont = s_ncont < CCAP ? s_ncont : CCAP;
             CRec* csorted = L.csorted;
-            for (int32_t q = tid; q < ncont; q += 256) {
+            for (int32_t q = tid; q < ncont; q += NT) {
                 CRec me = L.cont[q];
                 uint64_t kme = ((uint64_t)(uint32_t)me.x << 32) | (uint32_t)me.i;
                 int rank = 0;
@@ -805,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                 csorted[rank] = me;
             }
             __syncthreads();
-            for (int32_t q = tid; q < ncont; q += 256) {
+            for (int32_t q = tid; q < ncont; q += NT) {
                 if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;   // group head only
                 int32_t x = csorted[q].x;
                 int32_t key = use_pq ? A.key[x] : 1;
@@ -833,14 +1034,18 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                     if (R.mv >= 0) { ++mycnt; if (pq_list_of(R.key_after, n) <= G.minlist) pre = true; }
                 }
                 if (pre) atomicMin(&s_p, tid + 1);
-                // tcount back to zero for the next round
-                for (int32_t j = 0; j < C.m; ++j) tcount[C.e[j].nbr] = 0;
+            }
+            // tcount back to zero for the next round
+            for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
+                const int32_t i = idx / BCAP, j = idx % BCAP;
+                if (j < L.cand[i].m) tcount[L.cand[i].e[j].nbr] = 0;
             }
             int mtot;
             int mex = block_excl_scan(mycnt, L.scan, &mtot);
             if (tid < Pmax && mex + mycnt > MCAP) atomicMin(&s_p, tid);
             __syncthreads();
             P = s_p < Pmax ? s_p : Pmax;
+            PHASE_STAMP(4);
         }
         if (P == 0) {
             // ================= single-vertex path for candidate 0 =================
@@ -857,11 +1062,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                 int32_t cp0 = A.colptr[v0], cp1 = A.colptr[v0 + 1];
                 int32_t acnt = A.app_cnt[v0], abase = A.app_chunk[v0];
                 if ((cp1 - cp0) + acnt > ECAP) {
-                    if (lane == 0) {
-                        ColBuf Bf = S.colbuf(G.scr_base);
-                        int rc = serial_eliminate(A, G, Bf, G.scr_cap, v0, done + 1);
-                        if (rc) G.status = rc;
-                    }
+                    if (lane == 0) serial_eliminate_call(A, G, S, v0, done + 1);
                 } else {
                     wave_eliminate(A, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase);
                 }
@@ -869,6 +1070,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
             __syncthreads();
             if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
             done += 1;
+            PHASE_STAMP(5);
             continue;
         }
 
@@ -881,33 +1083,87 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
         if (tid < P) {
             Cand& C = L.cand[tid];
             if (use_pq) A.pqpos[C.v] = -2;
-            // targets touched by this candidate alone
-            for (int32_t j = 0; j < C.m; ++j) {
-                TRes R = ent_tres(C.e[j]);
-                if (R.flags & TF_CONTENDED) continue;
-                int32_t x = C.e[j].nbr;
-                if (R.c > 0) {
-                    int32_t a = A.app_cnt[x], chunk = A.app_chunk[x];
-                    push_into_target(A, C, j, a, chunk, &status);
-                    A.app_cnt[x] = a; A.app_chunk[x] = chunk;
+            // the edge to the last neighbour (or to the coarsening target) dies (:429-430 | :880-881)
+            if (C.m >= 1) A.e_val[C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin] = 0;
+        }
+        // targets touched by one candidate only: one thread per (candidate, target); two passes so that
+        // all loads are in flight together and the pool is bumped once per round
+        {
+            TRes Rk[PASSES]; int32_t xk[PASSES], a0k[PASSES], chk[PASSES], needk[PASSES]; bool actk[PASSES];
+            int32_t need_thread = 0;
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t idx = k * NT + tid;
+                const int32_t i = idx / BCAP, j = idx % BCAP;
+                actk[k] = false; xk[k] = 0; a0k[k] = 0; chk[k] = -1; needk[k] = 0;
+                Rk[k].key_after = 0; Rk[k].mv = -1; Rk[k].c = 0; Rk[k].flags = 0;
+                if (i < P && j < L.cand[i].m) {
+                    Rk[k] = ent_tres(L.cand[i].e[j]);
+                    xk[k] = L.cand[i].e[j].nbr;
+                    actk[k] = !(Rk[k].flags & TF_CONTENDED);
                 }
-                if (use_pq && R.mv >= 0) {
-                    A.key[x] = R.key_after;
+                if (actk[k] && Rk[k].c > 0) { a0k[k] = A.app_cnt[xk[k]]; chk[k] = A.app_chunk[xk[k]]; }
+            }
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                if (actk[k] && Rk[k].c > 0) {
+                    for (int32_t t = 0; t < (int32_t)Rk[k].c; ++t) {
+                        int32_t a = a0k[k] + t;
+                        int c = chunk_of(a);
+                        if (a == chunk_start(c)) needk[k] += 1 + chunk_cap(c);
+                    }
+                }
+                need_thread += needk[k];
+            }
+            int ntot;
+            int nex = block_excl_scan(need_thread, L.scan, &ntot);
+            if (tid == 0) {
+                int32_t base = 0;
+                if (ntot > 0) {
+                    base = atomicAdd(A.pool_top, ntot);
+                    if (base < 0 || base > A.slot_cap - ntot) base = -1;
+                }
+                L.scan[NWAVE + 1] = base;
+            }
+            __syncthreads();
+            const int32_t pbase = L.scan[NWAVE + 1];
+            if (pbase < 0) status = ST_POOL_OVERFLOW;
+            PHASE_STAMP(10);
+            int32_t cursor = pbase + nex;
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t idx = k * NT + tid;
+                const int32_t i = idx / BCAP, j = idx % BCAP;
+                if (actk[k] && Rk[k].c > 0 && status == 0) {
+                    const Cand& C = L.cand[i];
+                    int32_t a = a0k[k], chunk = chk[k];
+                    const bool co = A.o_v == OV_COARSEN;
+                    const int32_t plast = co ? C.m : C.m - 1;
+                    for (int32_t p = 0; p < plast; ++p) {
+                        if (co ? (p == C.koff) : (C.ksel[p] != j)) continue;
+                        int c = chunk_of(a);
+                        int32_t cs = chunk_start(c);
+                        if (a == cs) { A.e_nbr[cursor] = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
+                        L.pslot[i * BCAP + p] = chunk + 1 + (a - cs);
+                        ++a;
+                    }
+                    A.app_cnt[xk[k]] = a; A.app_chunk[xk[k]] = chunk;
+                }
+                if (use_pq && actk[k] && Rk[k].mv >= 0) {
+                    A.key[xk[k]] = Rk[k].key_after;
                     int32_t q = atomicAdd(&s_nmoves, 1);
                     if (q < MCAP) {
-                        L.mkey[q] = ((uint64_t)(uint32_t)pq_list_of(R.key_after, n) << 32) | (uint32_t)((tid << 8) | R.mv);
-                        L.mval[q] = x;
+                        L.mkey[q] = ((uint64_t)(uint32_t)pq_list_of(Rk[k].key_after, n) << 32) | (uint32_t)((i << 8) | Rk[k].mv);
+                        L.mval[q] = xk[k];
                     }
                 }
             }
-            // the edge to the last neighbour (or to the coarsening target) dies (:429-430 | :880-881)
-            if (C.m >= 1) A.e_val[C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin] = 0;
         }
         // targets shared by several candidates: one thread walks the target's records in candidate order
         {
             const int32_t ncont = s_ncont < CCAP ? s_ncont : CCAP;
             const CRec* csorted = L.csorted;
-            for (int32_t q = tid; q < ncont; q += 256) {
+            for (int32_t q = tid; q < ncont; q += NT) {
                 if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;
                 const int32_t x = csorted[q].x;
                 if (csorted[q].i >= P) continue;
@@ -916,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                 int32_t key_final = 0, mvseq = -1;
                 for (int32_t r = q; r < ncont && csorted[r].x == x && csorted[r].i < P; ++r) {
                     Cand& C = L.cand[csorted[r].i];
-                    push_into_target(A, C, csorted[r].j, a, chunk, &status);
+                    slots_into_target(A, C, csorted[r].j, a, chunk, &status, &L.pslot[csorted[r].i * BCAP]);
                     TRes R = ent_tres(C.e[csorted[r].j]);
                     key_final = R.key_after;
                     if (R.mv >= 0) mvseq = (csorted[r].i << 8) | R.mv;
@@ -935,33 +1191,90 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
             }
         }
         if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_POOL_OVERFLOW; __syncthreads(); break; }
+        PHASE_STAMP(6);
+        // one thread per appended entry: twin rewritten in place + the new entry (:404-414)
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
+            const int32_t idx = k * NT + tid;
+            const int32_t i = idx / BCAP, pp = idx % BCAP;
+            if (i < P) {
+                const Cand& C = L.cand[i];
+                const bool co = A.o_v == OV_COARSEN;
+                if (co ? (pp < C.m && pp != C.koff) : (pp < C.m - 1)) {
+                    const int32_t kk = co ? C.koff : (int32_t)C.ksel[pp];
+                    rewire_store(A, C.e[pp].twin, L.pslot[i * BCAP + pp], C.e[pp].nbr, C.e[kk].nbr, C.e[pp].val);
+                }
+            }
+        }
+        PHASE_STAMP(11);
         const int32_t nmoves = s_nmoves;
         if (nmoves > MCAP) { if (tid == 0) s_status = ST_INTERNAL; __syncthreads(); break; }
         if (use_pq && nmoves > 0) {
-            // ---- sort the moves by (bucket, op order): bitonic, keys are distinct ----
-            int32_t npow = 1;
-            while (npow < nmoves) npow <<= 1;
-            for (int32_t q = nmoves + tid; q < npow; q += 256) { L.mkey[q] = ~0ull; L.mval[q] = -1; }
-            __syncthreads();
-            for (int32_t k = 2; k <= npow; k <<= 1) {
-                for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                    for (int32_t t = tid; t < (npow >> 1); t += 256) {
-                        int32_t lo = ((t / jj) * (jj << 1)) + (t % jj);
-                        int32_t hi = lo + jj;
-                        bool up = ((lo & k) == 0);
-                        uint64_t klo = L.mkey[lo], khi = L.mkey[hi];
-                        if ((klo > khi) == up) {
-                            L.mkey[lo] = khi; L.mkey[hi] = klo;
-                            int32_t tv = L.mval[lo]; L.mval[lo] = L.mval[hi]; L.mval[hi] = tv;
+            // ---- sort the moves by (bucket, op order): bitonic, one element per thread; strides < 64 stay
+            //      inside the wave (shuffles), only the larger strides go through LDS.  Keys are packed
+            //      into 32 bits ((bucket - lowest bucket) << 15 | candidate << 8 | op) when they fit ----
+            {
+                uint64_t kq = tid < nmoves ? L.mkey[tid] : ~0ull;
+                int32_t vq = tid < nmoves ? L.mval[tid] : -1;
+                uint32_t bmin = tid < nmoves ? (uint32_t)(kq >> 32) : 0xFFFFFFFFu, bmax = tid < nmoves ? (uint32_t)(kq >> 32) : 0u;
+                for (int off = 32; off > 0; off >>= 1) { bmin = min(bmin, (uint32_t)__shfl_xor((int)bmin, off)); bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, off)); }
+                if (lane == 0) { L.scan[tid >> 6] = (int32_t)bmin; L.hidx[tid >> 6] = (int32_t)bmax; }
+                __syncthreads();
+                for (int w = 0; w < NWAVE; ++w) { bmin = min(bmin, (uint32_t)L.scan[w]); bmax = max(bmax, (uint32_t)L.hidx[w]); }
+                int32_t npow = 64;
+                while (npow < nmoves) npow <<= 1;
+                __syncthreads();
+                if (bmax - bmin < (1u << 16)) {
+                    uint32_t k32 = tid < nmoves ? ((((uint32_t)(kq >> 32) - bmin) << 15) | ((uint32_t)kq & 0x7FFFu)) : 0xFFFFFFFFu;
+                    uint32_t* lk = reinterpret_cast<uint32_t*>(L.mkey);
+                    for (int32_t k = 2; k <= npow; k <<= 1) {
+                        for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                            const bool take_min = (((tid & jj) == 0) == ((tid & k) == 0));
+                            uint32_t ko; int32_t vo;
+                            if (jj >= 64) {
+                                lk[tid] = k32; L.mval[tid] = vq;
+                                __syncthreads();
+                                ko = lk[tid ^ jj]; vo = L.mval[tid ^ jj];
+                                __syncthreads();
+                            } else {
+                                ko = (uint32_t)__shfl_xor((int)k32, jj);
+                                vo = __shfl_xor(vq, jj);
+                            }
+                            const bool swap = take_min ? (ko < k32) : (ko > k32);
+                            if (swap) { k32 = ko; vq = vo; }
                         }
                     }
                     __syncthreads();
+                    kq = (k32 == 0xFFFFFFFFu) ? ~0ull : ((((uint64_t)((k32 >> 15) + bmin)) << 32) | (uint64_t)(k32 & 0x7FFFu));
+                } else {
+                    for (int32_t k = 2; k <= npow; k <<= 1) {
+                        for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                            const bool take_min = (((tid & jj) == 0) == ((tid & k) == 0));
+                            uint64_t ko; int32_t vo;
+                            if (jj >= 64) {
+                                L.mkey[tid] = kq; L.mval[tid] = vq;
+                                __syncthreads();
+                                ko = L.mkey[tid ^ jj]; vo = L.mval[tid ^ jj];
+                                __syncthreads();
+                            } else {
+                                uint32_t lo32 = (uint32_t)kq, hi32 = (uint32_t)(kq >> 32);
+                                uint32_t olo = (uint32_t)__shfl_xor((int)lo32, jj), ohi = (uint32_t)__shfl_xor((int)hi32, jj);
+                                ko = ((uint64_t)ohi << 32) | olo;
+                                vo = __shfl_xor(vq, jj);
+                            }
+                            const bool swap = take_min ? (ko < kq) : (ko > kq);
+                            if (swap) { kq = ko; vq = vo; }
+                        }
+                    }
                 }
+                L.mkey[tid] = kq; L.mval[tid] = vq;
+                __syncthreads();
             }
+            PHASE_STAMP(7);
             // ---- bucket-group head index of every move (inclusive max scan) ----
             {
                 int32_t carry = 0;
-                for (int32_t c0 = 0; c0 < nmoves; c0 += 256) {
+                for (int32_t c0 = 0; c0 < nmoves; c0 += NT) {
                     int32_t r = c0 + tid;
                     int32_t hv = -1;
                     if (r < nmoves) {
@@ -978,13 +1291,13 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                     incl = max(incl, pre);
                     if (r < nmoves) L.hidx[r] = incl;
                     int32_t nc2 = carry;
-                    for (int w = 0; w < 4; ++w) nc2 = max(nc2, L.scan[w]);
+                    for (int w = 0; w < NWAVE; ++w) nc2 = max(nc2, L.scan[w]);
                     carry = nc2;
                     __syncthreads();
                 }
             }
             // ---- allocate new stack chunks, then write the entries ----
-            for (int32_t r = tid; r < nmoves; r += 256) {
+            for (int32_t r = tid; r < nmoves; r += NT) {
                 int32_t lst = (int32_t)(L.mkey[r] >> 32);
                 int32_t bk = G.bucket_base + lst;
                 int32_t a = A.bs_cnt[bk] + (r - L.hidx[r]);
@@ -998,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
             }
             if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_LOG_OVERFLOW; __syncthreads(); break; }
             const int32_t id0 = G.push_cnt;
-            for (int32_t r = tid; r < nmoves; r += 256) {
+            for (int32_t r = tid; r < nmoves; r += NT) {
                 int32_t lst = (int32_t)(L.mkey[r] >> 32);
                 int32_t bk = G.bucket_base + lst;
                 int32_t a = A.bs_cnt[bk] + (r - L.hidx[r]);
@@ -1010,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                 L.hidx[r] = a;   // remember the position for the group tail below
             }
             __syncthreads();
-            for (int32_t r = tid; r < nmoves; r += 256) {
+            for (int32_t r = tid; r < nmoves; r += NT) {
                 bool tail = (r == nmoves - 1) || ((uint32_t)(L.mkey[r + 1] >> 32) != (uint32_t)(L.mkey[r] >> 32));
                 if (tail) {
                     int32_t lst = (int32_t)(L.mkey[r] >> 32);
@@ -1028,6 +1341,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
                 G.push_cnt = id0 + nmoves;
             }
         }
+        PHASE_STAMP(8);
         // ---- round epilogue ----
         if (tid < nc) batch_pos[L.cand[tid].v] = -1;
         if (tid == 0) {
@@ -1043,6 +1357,7 @@ __global__ __launch_bounds__(256) void k_eliminate_batch(Arrays A, GraphDesc* __
         G.n_elim = (int32_t)nelim;
         if (s_status) G.status = s_status;
         G.pad0 = rounds; G.pad1 = singles;
+        if (S.prof && g == 0) { for (int q = 0; q < 22; ++q) S.prof[q] = s_prof[q]; S.prof[22] = rounds; S.prof[23] = singles; }
         gd[g] = G;
     }
 }

@@ -127,6 +127,15 @@ void mirror_sort_perm(const double* keys, int64_t n, int desc, int64_t* perm_out
     for (int64_t i = 0; i < n; ++i) perm_out[i] = r[i].idx;
 }
 
+// n <= 32: the stack-free variant used for batch candidates, on the (key,index) proxy view
+void mirror_sort_perm_small(const double* keys, int64_t n, int desc, int64_t* perm_out) {
+    Cand C;
+    for (int64_t i = 0; i < n; ++i) { C.e[i].aux = keys[i]; C.ksel[i] = (uint8_t)i; }
+    KIArr arr; arr.e = C.e; arr.ix = C.ksel;
+    if (desc) gs_std_sort_small<KI>(arr, (int)n, KIGreater()); else gs_std_sort_small<KI>(arr, (int)n, KILess());
+    for (int64_t i = 0; i < n; ++i) perm_out[i] = C.ksel[i];
+}
+
 void mirror_heapsort_perm(const double* keys, int64_t n, int desc, int64_t* perm_out) {
     std::vector<SRec> r((size_t)n);
     for (int64_t i = 0; i < n; ++i) { r[i].key = keys[i]; r[i].idx = (int32_t)i; r[i].aux = 0; }

@@ -36,6 +36,16 @@ def test_std_sort_emulation_matches_libstdcxx(host_mirror):
             assert np.array_equal(oracle.stdsort_perm(k, bool(desc)), _mperm(host_mirror, "mirror_sort_perm", k, desc))
 
 
+def test_small_stack_free_sort_matches_libstdcxx(host_mirror):
+    rng = np.random.RandomState(2)
+    for trial in range(3000):
+        n = int(rng.randint(1, 33))
+        kind = trial % 4
+        k = [np.ones(n), rng.randint(0, 3, size=n).astype(float), rng.rand(n), np.sort(rng.randint(0, 5, size=n))[::-1].astype(float)][kind]
+        for desc in (0, 1):
+            assert np.array_equal(oracle.stdsort_perm(k, bool(desc)), _mperm(host_mirror, "mirror_sort_perm_small", k, desc))
+
+
 def test_heap_sort_fallback_matches_partial_sort(host_mirror):
     rng = np.random.RandomState(1)
     for t in range(400):
@@ -84,3 +94,44 @@ def test_device_data_structures_match_oracle(host_mirror, o_v, o_n):
         a = oracle.approximate_cholesky(ei, w, n, n // 2, o_v, o_n, perm=perm, shuffle_seed=4)
         b, _ = _mirror(host_mirror, ei, w, n, n // 2, o_v, o_n, perm=perm, seed=4)
         assert np.array_equal(a, b), name
+
+
+def _mirror_batch(lib, ei, w, n, t, o_v, o_n, B, perm=None, seed=0):
+    E = ei.shape[1]
+    row = np.ascontiguousarray(ei[0])
+    col = np.ascontiguousarray(ei[1])
+    w = np.ones(E) if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    out = ctypes.POINTER(ctypes.c_double)()
+    rows = ctypes.c_int64()
+    order = np.full(max(n, 1), -1, dtype=np.int64)
+    stats = np.zeros(4, dtype=np.int64)
+    p = np.ascontiguousarray(perm, dtype=np.int64) if perm is not None else None
+    lib.mirror_approx_chol_batch.restype = ctypes.c_int
+    rc = lib.mirror_approx_chol_batch(
+        ctypes.c_void_p(row.ctypes.data), ctypes.c_void_p(col.ctypes.data), ctypes.c_void_p(w.ctypes.data),
+        ctypes.c_int64(E), ctypes.c_int64(n), ctypes.c_int64(t), oracle.O_V[o_v], oracle.O_N[o_n],
+        ctypes.c_void_p(p.ctypes.data) if p is not None else None, ctypes.c_uint64(seed), ctypes.c_int32(4 * E + 64),
+        ctypes.c_int32(B), ctypes.byref(out), ctypes.byref(rows), ctypes.c_void_p(order.ctypes.data),
+        ctypes.c_void_p(stats.ctypes.data))
+    assert rc == 0
+    m = rows.value
+    res = np.ctypeslib.as_array(out, shape=(max(m, 1) * 3,))[: 3 * m].copy().reshape(m, 3)
+    lib.mirror_free(out)
+    return res, order[:n], stats
+
+
+@pytest.mark.parametrize("o_v", ["degree", "random", "coarsen"])
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_batch_rounds_equal_sequential_order(host_mirror, o_v, o_n):
+    """The frontier kernel's round rules (predict B pops, commit the longest independent,
+    un-pre-empted prefix, RNG offsets by prefix sum, shared targets in candidate order)
+    replayed on the CPU: bit-exact against the oracle for any batch size."""
+    for name, ei, n in GRAPHS + [("BA1500_8", ba_graph(1500, 8, 3), 1500)]:
+        perm = np.random.RandomState(10).permutation(n) if o_v == "random" else None
+        for t in sorted({1, n // 2, n - 1}):
+            for wts in (None, sym_weights(ei, n, 5)):
+                a, oa = oracle.approximate_cholesky(ei, wts, n, t, o_v, o_n, perm=perm, shuffle_seed=3, return_order=True)
+                for B in (1, 7, 128):
+                    b, ob, _ = _mirror_batch(host_mirror, ei, wts, n, t, o_v, o_n, B, perm=perm, seed=3)
+                    assert np.array_equal(oa, ob), (name, t, B)
+                    assert a.shape == b.shape and np.array_equal(a, b), (name, t, B)

@@ -1,0 +1,90 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharded batched-graph mode
+(rlap_amd/distributed.py).  The per-rank compute is injected (the CPU oracle stands in
+for the HIP op, which needs a GPU); what is tested is the sharding, the all-gather of
+variable-length (m_g,3) blocks and the global row pointer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_compute(ei, w, node_ptr, nrem, o_v, o_n, seed):
+    import oracle
+    outs, ptr = [], [0]
+    G = node_ptr.numel() - 1
+    ei_np = ei.numpy()
+    for g in range(G):
+        lo, hi = int(node_ptr[g]), int(node_ptr[g + 1])
+        sel = (ei_np[1] >= lo) & (ei_np[1] < hi)
+        sub = ei_np[:, sel] - lo
+        sc = oracle.approximate_cholesky(sub, None, hi - lo, int(nrem[g]), o_v, o_n)
+        sc[:, :2] += lo
+        outs.append(sc)
+        ptr.append(ptr[-1] + sc.shape[0])
+    return torch.from_numpy(np.concatenate(outs, 0) if outs else np.zeros((0, 3))), torch.tensor(ptr, dtype=torch.int64)
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rlap_amd.distributed import shard_range, sharded_approximate_cholesky
+    from util import ba_graph
+    ns = [40, 1, 75, 120, 33]              # 5 graphs over 2 ranks: ragged shards (3 + 2)
+    eis = [torch.from_numpy(ba_graph(n, 3, 10 + g)) if n > 3 else torch.zeros((2, 0), dtype=torch.int64) for g, n in enumerate(ns)]
+    ts = [n // 2 for n in ns]
+    sc, rp = sharded_approximate_cholesky(eis, None, ns, ts, "degree", "asc", compute_fn=_oracle_compute)
+    lo, hi = shard_range(len(ns), rank, world)
+    ret[rank] = (sc.numpy(), rp.numpy(), (lo, hi))
+    dist.destroy_process_group()
+
+
+def test_sharded_batched_mode_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from util import ba_graph
+    ns = [40, 1, 75, 120, 33]
+    exp = []
+    for g, n in enumerate(ns):
+        ei = ba_graph(n, 3, 10 + g) if n > 3 else np.zeros((2, 0), dtype=np.int64)
+        exp.append(oracle.approximate_cholesky(ei, None, n, n // 2, "degree", "asc"))
+    for rank in range(world):
+        sc, rp, _ = ret[rank]
+        assert rp.shape[0] == len(ns) + 1
+        for g in range(len(ns)):
+            got = sc[rp[g]:rp[g + 1]]
+            assert got.shape == exp[g].shape and np.array_equal(got, exp[g]), (rank, g)
+    assert ret[0][2] == (0, 3) and ret[1][2] == (3, 5)
+
+
+def test_shard_range_partitions_everything():
+    from rlap_amd.distributed import shard_range
+    for G in (0, 1, 7, 8, 1024):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_range(G, r, world)
+                cover.extend(range(lo, hi))
+            assert cover == list(range(G))
