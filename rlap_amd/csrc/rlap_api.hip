@@ -58,7 +58,7 @@ struct rlap_handle_s {
     int64_t rng_len = 0;
     DevBuf scr_rec, scr_i32, scr_f64;
     // output
-    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, counters;
+    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, counters, biglist;
     // growth factors kept across calls
     double pool_factor = 1.0;
     double log_factor = 2.0;
@@ -344,6 +344,21 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
                            h->tmp_off.as<int64_t>(), (int32_t)S, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1);
         HIPCHK(hipGetLastError());
     }
+    if (S > 0) {
+        // long columns: whole column in LDS, one single-wave workgroup each
+        ENSURE(h->biglist, 4 * (S + 1));
+        int32_t* bigcount = reinterpret_cast<int32_t*>(counters + 3);
+        const int keyed = (c.o_n == ON_RANDOM || c.o_v == OV_COARSEN) ? 1 : 0;
+        hipLaunchKernelGGL(k_sc_biglist, dim3(nblk(S, 256)), dim3(256), 0, s, h->ext.as<int32_t>(), (int32_t)S, keyed, h->biglist.as<int32_t>(), bigcount);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIGCAP * 16));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s, A, order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
+                           h->biglist.as<int32_t>(), bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1);
+        HIPCHK(hipGetLastError());
+    }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[4], s));
     { int rc = excl_scan(h, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), S + 1); if (rc) return rc; }
     int64_t m_total = 0;
@@ -406,7 +421,7 @@ int rlap_destroy(rlap_handle h) {
                       &h->deg, &h->colptr, &h->slot_col, &h->gcol, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
                       &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->tcount, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
-                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters};
+                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters, &h->biglist};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     delete h;

@@ -1450,8 +1450,10 @@ __global__ __launch_bounds__(64) void k_sc_merge(Arrays A, const GraphDesc* __re
         const int64_t toff = tmp_off[i];
         const int32_t ex = ext[i];
         if (ex > SCAP) {
-            // long column: sequential form in global scratch (one lane)
-            if (lane == 0) {
+            // long column: k_sc_merge_big takes it (LDS), unless it is too long for that or the order is keyed:
+            // then the sequential form in global scratch (one lane)
+            const bool keyed_order = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
+            if (lane == 0 && (keyed_order || ex > BIGCAP)) {
                 unsigned long long off = atomicAdd(SS.top, (unsigned long long)ex);
                 ColBuf B = SS.colbuf((int64_t)off);
                 GraphDesc D = gd[vgraph[v]];
@@ -1574,6 +1576,149 @@ __global__ __launch_bounds__(64) void k_sc_merge(Arrays A, const GraphDesc* __re
             tmp_nbr[toff + j] = L.b_nbr[x];
             tmp_val[toff + j] = L.b_val[x];
         }
+        if (lane == 0) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)len0); }
+        __syncthreads();
+    }
+}
+
+// Long columns (SCAP < extent <= BIGCAP): one single-wave workgroup per column with the whole
+// column in LDS as 16-byte records {id as double, weight}; both sorts are the std::sort emulation
+// run by one lane on LDS (exact under ties), gather / merge bookkeeping / stores by the wave.
+struct Rec2 { double a; double b; };
+struct Rec2LessA { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.a < y.a; } };
+struct Rec2LessB { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.b < y.b; } };
+struct Rec2GreaterB { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.b > y.b; } };
+
+__global__ void k_sc_biglist(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ list, int32_t* __restrict__ count) {
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S || keyed) return;
+    int32_t e = ext[i];
+    if (e > SCAP && e <= BIGCAP) list[atomicAdd(count, 1)] = i;
+}
+
+__global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+                                                     const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
+                                                     const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
+                                                     double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
+                                                     unsigned long long* __restrict__ live_total) {
+    extern __shared__ Rec2 R[];   // BIGCAP records
+    __shared__ int32_t s_m;
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt(lane);
+    const int32_t nbig = *count;
+    for (int32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        const int32_t i = list[bi];
+        const int32_t v = (int32_t)order[i];
+        const int64_t toff = tmp_off[i];
+        const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
+        const int32_t acnt = A.app_cnt[v];
+        int len0 = 0;
+        {
+            int32_t idx = acnt - 1, base = A.app_chunk[v];
+            int c = idx >= 0 ? chunk_of(idx) : 0;
+            while (idx >= 0) {
+                int32_t cs = chunk_start(c);
+                for (int32_t t0 = idx; t0 >= cs; t0 -= 64) {
+                    int32_t t = t0 - lane;
+                    bool valid = t >= cs;
+                    int32_t s = base + 1 + (t - cs);
+                    double val = 0; int32_t nb = 0;
+                    if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                    bool live = valid && val > 0;
+                    uint64_t mask = __ballot(live);
+                    int pos = len0 + popc64(mask & lt);
+                    if (live) { R[pos].a = (double)nb; R[pos].b = val; }
+                    len0 += popc64(mask);
+                }
+                int32_t prev = A.e_nbr[base];
+                idx = cs - 1; base = prev; --c;
+            }
+            for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
+                int32_t s = s0 - lane;
+                bool valid = s >= cp0;
+                double val = 0; int32_t nb = 0;
+                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                bool live = valid && val > 0;
+                uint64_t mask = __ballot(live);
+                int pos = len0 + popc64(mask & lt);
+                if (live) { R[pos].a = (double)nb; R[pos].b = val; }
+                len0 += popc64(mask);
+            }
+        }
+        __syncthreads();
+        // sort by id (:314-315).  Distinct ids have one sorted order, so a wave-parallel bitonic sort is
+        // exact; if a multi-edge shows up, gather again and let one lane emulate std::sort.
+        bool exact_needed = false;
+        {
+            int32_t npow = 64;
+            while (npow < len0) npow <<= 1;
+            for (int32_t q = len0 + lane; q < npow; q += 64) { R[q].a = 1e300; R[q].b = 0; }
+            __syncthreads();
+            for (int32_t k = 2; k <= npow; k <<= 1) {
+                for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int32_t t = lane; t < (npow >> 1); t += 64) {
+                        int32_t lo = ((t / jj) * (jj << 1)) + (t % jj);
+                        int32_t hi = lo + jj;
+                        bool up = ((lo & k) == 0);
+                        Rec2 x = R[lo], y = R[hi];
+                        if ((x.a > y.a) == up) { R[lo] = y; R[hi] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+            bool dup = false;
+            for (int32_t q = 1 + lane; q < len0; q += 64) dup |= (R[q].a == R[q - 1].a);
+            exact_needed = __ballot(dup) != 0ull;
+        }
+        if (exact_needed) {
+            // rare: re-gather in traversal order for the exact emulation
+            __syncthreads();
+            len0 = 0;
+            int32_t idx = acnt - 1, base = A.app_chunk[v];
+            int c = idx >= 0 ? chunk_of(idx) : 0;
+            while (idx >= 0) {
+                int32_t cs = chunk_start(c);
+                for (int32_t t0 = idx; t0 >= cs; t0 -= 64) {
+                    int32_t t = t0 - lane;
+                    bool valid = t >= cs;
+                    int32_t s = base + 1 + (t - cs);
+                    double val = 0; int32_t nb = 0;
+                    if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                    bool live = valid && val > 0;
+                    uint64_t mask = __ballot(live);
+                    int pos = len0 + popc64(mask & lt);
+                    if (live) { R[pos].a = (double)nb; R[pos].b = val; }
+                    len0 += popc64(mask);
+                }
+                int32_t prev = A.e_nbr[base];
+                idx = cs - 1; base = prev; --c;
+            }
+            for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
+                int32_t s = s0 - lane;
+                bool valid = s >= cp0;
+                double val = 0; int32_t nb = 0;
+                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                bool live = valid && val > 0;
+                uint64_t mask = __ballot(live);
+                int pos = len0 + popc64(mask & lt);
+                if (live) { R[pos].a = (double)nb; R[pos].b = val; }
+                len0 += popc64(mask);
+            }
+            __syncthreads();
+        }
+        if (lane == 0) {
+            if (exact_needed) gs_std_sort<Rec2>(R, len0, Rec2LessA());
+            int32_t m = 0;
+            for (int32_t q = 0; q < len0; ++q) {               // :317-329
+                if (m == 0 || R[q].a != R[m - 1].a) { R[m] = R[q]; ++m; }
+                else R[m - 1].b += R[q].b;
+            }
+            if (A.o_n == ON_ASC) gs_std_sort<Rec2>(R, m, Rec2LessB()); else gs_std_sort<Rec2>(R, m, Rec2GreaterB());   // :331-338
+            s_m = m;
+        }
+        __syncthreads();
+        const int32_t m = s_m;
+        for (int32_t j = lane; j < m; j += 64) { tmp_nbr[toff + j] = (int32_t)R[j].a; tmp_val[toff + j] = R[j].b; }
         if (lane == 0) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)len0); }
         __syncthreads();
     }
