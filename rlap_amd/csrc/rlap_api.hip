@@ -375,7 +375,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[5], s));
     if (S > 0 && m_total > 0) {
-        unsigned grid = (unsigned)std::min<int64_t>((S + 3) / 4, 256 * 8);
+        unsigned grid = (unsigned)std::min<int64_t>((m_total + 255) / 256, 256 * 8);
         hipLaunchKernelGGL(k_sc_compact, dim3(grid), dim3(256), 0, s, order, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), h->tmp_off.as<int64_t>(),
                            h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), (int32_t)S, c.d_out);
         HIPCHK(hipGetLastError());

@@ -1724,25 +1724,86 @@ __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* _
     }
 }
 
-// Pass B: rows of vertex order[i] go to out[3*row_off[i] ...]; fully coalesced
-// 8-byte stores (element d of the vertex's 3*cnt doubles -> row d/3, field d%3).
+// Pass B (the prefix-sum compaction): row r of the output belongs to the surviving vertex i with
+// row_off[i] <= r < row_off[i+1].  One lane per ROW (tiles of 64 consecutive rows per wave, a
+// contiguous run of tiles per wave), so lanes stay busy whatever the column lengths are; the
+// owner of each row is found in the tile's window of row_off by a 6-step search over lane
+// registers, and the 64x3 doubles are staged through LDS so that every store is a contiguous
+// 512-byte wave store.
 __global__ __launch_bounds__(256) void k_sc_compact(const uint32_t* __restrict__ order, const int32_t* __restrict__ cnt,
                                                     const int64_t* __restrict__ row_off, const int64_t* __restrict__ tmp_off,
                                                     const int32_t* __restrict__ tmp_nbr, const double* __restrict__ tmp_val,
                                                     int32_t S, double* __restrict__ out) {
+    (void)cnt;
+    __shared__ double stage[4][192];
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int32_t i = wave; i < S; i += nwaves) {
-        const int32_t c = cnt[i];
-        const double vcol = (double)order[i];
-        const int64_t ro = row_off[i], to = tmp_off[i];
-        double* o = out + 3 * ro;
-        for (int32_t d = lane; d < 3 * c; d += 64) {
-            int32_t r = d / 3, f = d - 3 * r;
-            double val = f == 0 ? (double)tmp_nbr[to + r] : (f == 1 ? vcol : tmp_val[to + r]);
-            o[d] = val;
+    const int wv = threadIdx.x >> 6;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t m_total = row_off[S];
+    const int64_t ntiles = (m_total + 63) >> 6;
+    const int64_t per = (ntiles + nwaves - 1) / nwaves;
+    int64_t t0 = wave * per, t1 = t0 + per;
+    if (t1 > ntiles) t1 = ntiles;
+    if (t0 >= t1) return;
+    // owner of the first row of this wave's run: last i with row_off[i] <= r
+    int32_t i0;
+    {
+        const int64_t r = t0 << 6;
+        int32_t lo = 0, hi = S;   // invariant: row_off[lo] <= r < row_off[hi] (row_off[S] = m_total > r)
+        while (hi - lo > 1) {
+            int32_t mid = (lo + hi) >> 1;
+            if (row_off[mid] <= r) lo = mid; else hi = mid;
         }
+        i0 = lo;
+    }
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t r = (t << 6) + lane;
+        const bool valid = r < m_total;
+        int32_t owner = i0;
+        int64_t obase = 0;
+        // window search; windows advance by 63 while some lane's row lies beyond the window
+        int32_t wbase = i0;
+        bool found = false;
+        while (true) {
+            int32_t idx = wbase + lane;
+            int64_t ro = row_off[idx <= S ? idx : S];
+            // largest p in [0,63] with ro_p <= r
+            int p = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                int q = p + step;
+                int64_t rq = __shfl(ro, q);
+                if (rq <= r) p = q;
+            }
+            int64_t rp = __shfl(ro, p);
+            bool inside = (p < 63) || (wbase + 63 >= S);   // p == 63 may mean "further right"
+            if (!found && (inside || !valid)) { owner = wbase + p; obase = rp; found = true; }
+            if (__ballot(!found) == 0ull) break;
+            wbase += 63;
+        }
+        if (owner >= S) owner = S - 1;
+        double f0 = 0, f1 = 0, f2 = 0;
+        if (valid) {
+            const int64_t src = tmp_off[owner] + (r - obase);
+            f0 = (double)tmp_nbr[src];
+            f1 = (double)order[owner];
+            f2 = tmp_val[src];
+        }
+        double* st = stage[wv];
+        st[lane * 3 + 0] = f0; st[lane * 3 + 1] = f1; st[lane * 3 + 2] = f2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t o0 = (t << 6) * 3;
+        const int64_t lim = m_total * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int64_t d = o0 + lane + 64 * k;
+            if (d < lim) out[d] = st[lane + 64 * k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        i0 = __shfl(owner, 63);
     }
 }
 
