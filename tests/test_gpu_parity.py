@@ -189,3 +189,45 @@ def test_determinism_run_twice(ops):
     a = gpu_call(ops, ei, None, n, n // 2, "degree", "asc")
     b = gpu_call(ops, ei, None, n, n // 2, "degree", "asc")
     assert np.array_equal(a, b)
+
+
+def test_device_native_adapters(ops):
+    # the PyGCL-style adapter (scripts/augmentor_benchmarks.py:75-96) without leaving the GPU
+    from rlap_amd.adapters import rLap, rLapDGL
+    n = 400
+    ei = ba_graph(n, 5, 12)
+    x = torch.randn(n, 8, device="cuda")
+    aug = rLap(0.5, o_v="degree", o_n="asc")
+    g = aug(x, torch.from_numpy(ei).cuda(), None)
+    ref = oracle.approximate_cholesky(ei, None, n, n // 2, "degree", "asc")
+    assert g.edge_index.is_cuda and g.edge_weights is None and g.x is x
+    assert np.array_equal(g.edge_index.cpu().numpy(), ref[:, :2].astype(np.int64).T)
+    gw = rLap(0.5, o_v="degree", o_n="asc", keep_weights=True)(x, torch.from_numpy(ei).cuda(), None)
+    assert np.array_equal(gw.edge_weights.cpu().numpy(), ref[:, 2])
+    ei2, nn = rLapDGL(0.5, o_v="degree", o_n="asc").augment((torch.from_numpy(ei).cuda(), n))
+    assert nn == n and np.array_equal(ei2.cpu().numpy(), ref[:, :2].astype(np.int64).T)
+
+
+def test_large_graph_properties(ops):
+    """Size-independent checks at a size the oracle is not run for (invariants of a16-a19)."""
+    from rlap_amd import graphs
+    n = 300_000
+    ei = graphs.barabasi_albert(n, 6, 77).cuda()
+    for o_v in ("degree", "coarsen"):
+        sc = ops.approximate_cholesky(ei, None, n, n // 2, o_v, "asc", seed=3, return_device="same")
+        r, c, w = sc[:, 0].long(), sc[:, 1].long(), sc[:, 2]
+        assert (w > 0).all()
+        # every surviving undirected edge appears exactly twice, once per direction, with matching weights
+        key_f = r * n + c
+        key_b = c * n + r
+        sf, of = torch.sort(key_f)
+        sb, ob = torch.sort(key_b)
+        assert torch.equal(sf, sb)
+        assert torch.allclose(w[of], w[ob], rtol=1e-12, atol=0)
+        assert (sf[1:] != sf[:-1]).all()                      # multi-edges were merged
+        # exactly n - min(t, n-1) vertices may appear as columns; none of them eliminated twice
+        cols = torch.unique(c)
+        assert cols.numel() <= n - n // 2
+        # run twice: same result (deterministic for degree; coarsen with a fixed seed)
+        sc2 = ops.approximate_cholesky(ei, None, n, n // 2, o_v, "asc", seed=3, return_device="same")
+        assert torch.equal(sc, sc2)
