@@ -289,7 +289,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         long long pr[24];
         HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
         const char* names[15] = {"P0 select", "P1c4 permute", "P1b depend", "P2+P3 offsets+sample", "P4 replay", "single path", "P5b slots+contended", "moves sort", "pushes", "P1ab meta+loads", "P5a loads+scan+bump", "P5c rewire stores", "P1c1 rank", "P1c2 write", "P1c3 order-index"};
-        std::fprintf(stderr, "[rlap phase profile] rounds=%lld singles=%lld (100 MHz ticks)\n", pr[22], pr[23]);
+        std::fprintf(stderr, "[rlap phase profile] rounds=%lld singles=%lld (100 MHz ticks); shader clock over the kernel: %.0f MHz\n", pr[22], pr[23], pr[21] > 0 ? 100.0 * (double)pr[20] / (double)pr[21] : 0.0);
         for (int k = 0; k < 15; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
     }
     for (int64_t g = 0; g < G; ++g) {

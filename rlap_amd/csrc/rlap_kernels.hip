@@ -698,7 +698,8 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
     long long t_prev = 0;
     __shared__ long long s_prof[24];   // diagnostic build only (S.prof != nullptr)
 #define PHASE_STAMP(k) do { if (S.prof && tid == 0 && g == 0) { long long _t = wall_clock64(); s_prof[k] += _t - t_prev; t_prev = _t; } } while (0)
-    if (S.prof && tid == 0 && g == 0) { for (int q = 0; q < 24; ++q) s_prof[q] = 0; t_prev = wall_clock64(); }
+    long long clk0 = 0, wall0 = 0;
+    if (S.prof && tid == 0 && g == 0) { for (int q = 0; q < 24; ++q) s_prof[q] = 0; t_prev = wall_clock64(); clk0 = clock64(); wall0 = t_prev; }
 
     while (done < nelim) {
         ++rounds;
@@ -932,8 +933,9 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
         PHASE_STAMP(1);
         // ================= P1b: first candidate that depends on an earlier one =================
         if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);
-        for (int32_t idx = tid; idx < nc * BCAP; idx += NT) {
-            const int32_t i = idx / BCAP, j = idx % BCAP;
+        for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+            const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+            if (i >= nc) continue;
             if (j < L.cand[i].m) {
                 int32_t bp = batch_pos[L.cand[i].e[j].nbr];
                 if (bp >= 0 && bp < i) atomicMin(&s_pmax, i);
@@ -955,8 +957,9 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             }
             __syncthreads();
             if (A.o_v != OV_COARSEN) {
-                for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
-                    const int32_t i = idx / BCAP, j = idx % BCAP;
+                for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+                    const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                    if (i >= Pmax) continue;
                     if (j < L.cand[i].m - 1) cand_pick(A, L.cand[i], j);
                 }
                 if (tid < Pmax) cand_recur(A, L.cand[tid]);   // touches e[].val only
@@ -964,13 +967,15 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             __syncthreads();
             PHASE_STAMP(3);
             // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
-            for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
-                const int32_t i = idx / BCAP, j = idx % BCAP;
+            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                if (i >= Pmax) continue;
                 if (j < L.cand[i].m) atomicAdd(&tcount[L.cand[i].e[j].nbr], 1);
             }
             __syncthreads();
-            for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
-                const int32_t i = idx / BCAP, j = idx % BCAP;
+            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                if (i >= Pmax) continue;
                 Cand& C = L.cand[i];
                 if (j >= C.m) continue;
                 const int32_t x = C.e[j].nbr;
@@ -1036,8 +1041,9 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                 if (pre) atomicMin(&s_p, tid + 1);
             }
             // tcount back to zero for the next round
-            for (int32_t idx = tid; idx < Pmax * BCAP; idx += NT) {
-                const int32_t i = idx / BCAP, j = idx % BCAP;
+            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                if (i >= Pmax) continue;
                 if (j < L.cand[i].m) tcount[L.cand[i].e[j].nbr] = 0;
             }
             int mtot;
@@ -1059,12 +1065,17 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             }
             __syncthreads();
             if (tid < 64) {
-                int32_t cp0 = A.colptr[v0], cp1 = A.colptr[v0 + 1];
-                int32_t acnt = A.app_cnt[v0], abase = A.app_chunk[v0];
+                // the out-of-line paths take the descriptors by reference: hand them private copies so that
+                // the kernel's own copy never has its address taken (it would otherwise live in scratch
+                // memory and every A.member access in the hot phases would be a scratch load)
+                Arrays A2 = A;
+                ElimScratch S2 = S;
+                int32_t cp0 = A2.colptr[v0], cp1 = A2.colptr[v0 + 1];
+                int32_t acnt = A2.app_cnt[v0], abase = A2.app_chunk[v0];
                 if ((cp1 - cp0) + acnt > ECAP) {
-                    if (lane == 0) serial_eliminate_call(A, G, S, v0, done + 1);
+                    if (lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
                 } else {
-                    wave_eliminate(A, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase);
+                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase);
                 }
             }
             __syncthreads();
@@ -1093,8 +1104,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             int32_t need_thread = 0;
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t idx = k * NT + tid;
-                const int32_t i = idx / BCAP, j = idx % BCAP;
+                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                 actk[k] = false; xk[k] = 0; a0k[k] = 0; chk[k] = -1; needk[k] = 0;
                 Rk[k].key_after = 0; Rk[k].mv = -1; Rk[k].c = 0; Rk[k].flags = 0;
                 if (i < P && j < L.cand[i].m) {
@@ -1132,8 +1142,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             int32_t cursor = pbase + nex;
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t idx = k * NT + tid;
-                const int32_t i = idx / BCAP, j = idx % BCAP;
+                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                 if (actk[k] && Rk[k].c > 0 && status == 0) {
                     const Cand& C = L.cand[i];
                     int32_t a = a0k[k], chunk = chk[k];
@@ -1149,9 +1158,16 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                     }
                     A.app_cnt[xk[k]] = a; A.app_chunk[xk[k]] = chunk;
                 }
-                if (use_pq && actk[k] && Rk[k].mv >= 0) {
+                const bool mvd = use_pq && actk[k] && Rk[k].mv >= 0;
+                const uint64_t mvmask = __ballot(mvd);
+                int32_t qbase = 0;
+                if (mvmask) {   // one LDS atomic per wave instead of one per move
+                    if (lane == __builtin_ctzll(mvmask)) qbase = atomicAdd(&s_nmoves, __popcll(mvmask));
+                    qbase = __shfl(qbase, __builtin_ctzll(mvmask));
+                }
+                if (mvd) {
                     A.key[xk[k]] = Rk[k].key_after;
-                    int32_t q = atomicAdd(&s_nmoves, 1);
+                    int32_t q = qbase + __popcll(mvmask & lanemask_lt(lane));
                     if (q < MCAP) {
                         L.mkey[q] = ((uint64_t)(uint32_t)pq_list_of(Rk[k].key_after, n) << 32) | (uint32_t)((i << 8) | Rk[k].mv);
                         L.mval[q] = xk[k];
@@ -1195,8 +1211,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
         // one thread per appended entry: twin rewritten in place + the new entry (:404-414)
 #pragma unroll
         for (int k = 0; k < PASSES; ++k) {
-            const int32_t idx = k * NT + tid;
-            const int32_t i = idx / BCAP, pp = idx % BCAP;
+            const int32_t i = tid / (NT / BATCH), pp = k * (NT / BATCH) + tid % (NT / BATCH);
             if (i < P) {
                 const Cand& C = L.cand[i];
                 const bool co = A.o_v == OV_COARSEN;
@@ -1357,7 +1372,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
         G.n_elim = (int32_t)nelim;
         if (s_status) G.status = s_status;
         G.pad0 = rounds; G.pad1 = singles;
-        if (S.prof && g == 0) { for (int q = 0; q < 22; ++q) S.prof[q] = s_prof[q]; S.prof[22] = rounds; S.prof[23] = singles; }
+        if (S.prof && g == 0) { for (int q = 0; q < 20; ++q) S.prof[q] = s_prof[q]; S.prof[20] = clock64() - clk0; S.prof[21] = wall_clock64() - wall0; S.prof[22] = rounds; S.prof[23] = singles; }
         gd[g] = G;
     }
 }
