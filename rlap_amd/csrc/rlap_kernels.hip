@@ -678,7 +678,6 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     if (tid == 0) { G = gd[g]; s_status = 0; }
     if (tid < 16) {
         Cand& C = L.cand[tid];
@@ -702,6 +701,13 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
     if (S.prof && tid == 0 && g == 0) { for (int q = 0; q < 24; ++q) s_prof[q] = 0; t_prev = wall_clock64(); clk0 = clock64(); wall0 = t_prev; }
 
     while (done < nelim) {
+        // per-round opaque copy of the thread id: keeps the compiler from hoisting the (cheap) per-pass index
+        // and LDS-address arithmetic out of the round loop, where it would stay live across every barrier
+        // and get spilled to scratch memory
+        int tid_round = threadIdx.x;
+        asm volatile("" : "+v"(tid_round));
+        const int tid = tid_round;
+        const int lane = tid & 63;
         ++rounds;
         const int32_t Bcur = (int32_t)((nelim - done) < (int64_t)BATCH ? (nelim - done) : (int64_t)BATCH);
         // ================= P0: predict the next pops =================

@@ -1,0 +1,31 @@
+"""BASELINE config 5: batch of 1024 BA(4096, m=8) graphs, num_remove = N/2 each, one launch.
+Checks a sample of graphs against the oracle and reports throughput."""
+import sys, time
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np, torch
+from rlap_amd import graphs, ops
+import oracle
+G, n, m = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 4096, 8
+eis = [graphs.barabasi_albert(n, m, 1000 + g) for g in range(G)]
+big, node_ptr = graphs.batch_disjoint(eis, [n] * G)
+big = big.cuda()
+ts = [n // 2] * G
+ops.set_timing(True)
+for o_v in ("degree", "random"):
+    perms = [np.random.RandomState(g).permutation(n) for g in range(G)]
+    perm = torch.from_numpy(np.concatenate(perms)) if o_v == "random" else None
+    sc, rp = ops.approximate_cholesky_batched(big, None, node_ptr, ts, o_v, "asc", perm=perm, seed=5)   # warm-up (allocations)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sc, rp = ops.approximate_cholesky_batched(big, None, node_ptr, ts, o_v, "asc", perm=perm, seed=5)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = ops.last_stats
+    print(f"{o_v}/asc: G={G} graphs x {n} nodes: {dt*1e3:.1f} ms  -> {G*(n//2)/dt:.3e} eliminated vertices/s, {int(rp[-1])/dt:.3e} output edges/s; phases {st['ms_setup']:.1f}/{st['ms_elim']:.1f}/{st['ms_output']:.1f} ms")
+    sc = sc.cpu().numpy()
+    bad = 0
+    for g in list(range(0, G, max(1, G // 16))):
+        ref = oracle.approximate_cholesky(eis[g].numpy(), None, n, n // 2, o_v, "asc", perm=perms[g])
+        got = sc[int(rp[g]):int(rp[g + 1])].copy(); got[:, :2] -= g * n
+        bad += not (got.shape == ref.shape and np.array_equal(got, ref))
+    print("  oracle check on 16 graphs: mismatches =", bad)
