@@ -56,6 +56,60 @@ class rLap:
         return self.augment(Graph(x, edge_index, edge_weight))
 
 
+def compute_ppr(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int, alpha: float = 0.2,
+                eps: float = 1e-4, add_self_loop: bool = False):
+    """Dense personalised-PageRank diffusion, S = alpha (I - (1-alpha) D^-1/2 A D^-1/2)^-1, entries
+    below `eps` dropped -- the closed form PyGCL's `compute_ppr` evaluates
+    (scripts/augmentor_benchmarks.py:152-159 calls it with ignore_edge_attr=False,
+    add_self_loop=False).  torch ops on the input's device; meant for the sizes the reference
+    uses it on (the Schur-complement subgraph)."""
+    dev = edge_index.device
+    w = torch.ones(edge_index.shape[1], dtype=torch.float64, device=dev) if edge_weight is None else edge_weight.to(torch.float64)
+    adj = torch.zeros((num_nodes, num_nodes), dtype=torch.float64, device=dev)
+    adj.index_put_((edge_index[0], edge_index[1]), w, accumulate=True)
+    if add_self_loop:
+        adj = adj + torch.eye(num_nodes, dtype=torch.float64, device=dev)
+    deg = adj.sum(1)
+    dinv = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    a_hat = dinv[:, None] * adj * dinv[None, :]
+    s = alpha * torch.linalg.inv(torch.eye(num_nodes, dtype=torch.float64, device=dev) - (1 - alpha) * a_hat)
+    s = torch.where(s >= eps, s, torch.zeros_like(s))
+    idx = s.nonzero(as_tuple=False).t().contiguous()
+    return idx, s[idx[0], idx[1]]
+
+
+class rLapPPRDiffusion:
+    """scripts/augmentor_benchmarks.py:99-171: Schur complement (weights kept) -> induced subgraph on
+    the surviving nodes, relabelled -> PPR diffusion -> original ids; result cached for
+    `refresh_cache_freq` calls like the reference."""
+
+    def __init__(self, frac, o_v="random", o_n="asc", alpha=0.2, eps=1e-4, use_cache=True, refresh_cache_freq=50, seed=None):
+        self.frac, self.o_v, self.o_n, self.alpha, self.eps = frac, o_v, o_n, alpha, eps
+        self.use_cache, self.refresh_cache_freq = use_cache, refresh_cache_freq
+        self._cache, self.refresh_cache_counter, self.seed = None, 0, seed
+
+    def augment(self, g):
+        if self._cache is not None and self.use_cache and self.refresh_cache_counter < self.refresh_cache_freq:
+            self.refresh_cache_counter += 1
+            return self._cache
+        x, edge_index, edge_weights = g.unfold() if hasattr(g, "unfold") else g
+        num_nodes = _num_nodes(edge_index, x)
+        sc = ops.approximate_cholesky(edge_index, edge_weights, num_nodes, int(self.frac * num_nodes), self.o_v, self.o_n,
+                                      seed=self.seed, return_device="same")
+        ei = sc[:, :2].long().t()
+        nodes = torch.unique(ei, sorted=True)                       # surviving nodes that still have edges
+        relabel = torch.full((num_nodes,), -1, dtype=torch.int64, device=ei.device)
+        relabel[nodes] = torch.arange(nodes.numel(), device=ei.device)
+        sub_ei = relabel[ei]
+        d_ei, d_w = compute_ppr(sub_ei, sc[:, 2], nodes.numel(), alpha=self.alpha, eps=self.eps)
+        res = Graph(x, nodes[d_ei], d_w)
+        self._cache, self.refresh_cache_counter = res, 0
+        return res
+
+    def __call__(self, x, edge_index, edge_weight=None):
+        return self.augment(Graph(x, edge_index, edge_weight))
+
+
 class rLapDGL:
     """DGL-style augmentor (CCA-SSG/aug.py:33-63): edges -> (2,E) -> op (edge_weights=None) -> new graph."""
 

@@ -208,6 +208,29 @@ def test_device_native_adapters(ops):
     assert nn == n and np.array_equal(ei2.cpu().numpy(), ref[:, :2].astype(np.int64).T)
 
 
+def test_ppr_diffusion_adapter(ops):
+    # the only caller that uses the output WEIGHTS (augmentor_benchmarks.py:121-171)
+    from rlap_amd.adapters import rLapPPRDiffusion, compute_ppr
+    n = 300
+    ei = ba_graph(n, 4, 21)
+    x = torch.randn(n, 4, device="cuda")
+    aug = rLapPPRDiffusion(0.5, o_v="degree", o_n="asc", alpha=0.2, eps=1e-4)
+    g = aug(x, torch.from_numpy(ei).cuda(), None)
+    # same thing from the oracle's output with numpy
+    ref = oracle.approximate_cholesky(ei, None, n, n // 2, "degree", "asc")
+    nodes = np.unique(ref[:, :2].astype(np.int64))
+    rel = -np.ones(n, dtype=np.int64); rel[nodes] = np.arange(len(nodes))
+    A = np.zeros((len(nodes), len(nodes)))
+    np.add.at(A, (rel[ref[:, 0].astype(int)], rel[ref[:, 1].astype(int)]), ref[:, 2])
+    d = A.sum(1); dinv = np.where(d > 0, d ** -0.5, 0)
+    S = 0.2 * np.linalg.inv(np.eye(len(nodes)) - 0.8 * (dinv[:, None] * A * dinv[None, :]))
+    S[S < 1e-4] = 0
+    got = np.zeros_like(S)
+    gi = g.edge_index.cpu().numpy(); got[rel[gi[0]], rel[gi[1]]] = g.edge_weights.cpu().numpy()
+    assert np.allclose(got, S, rtol=1e-8, atol=1e-12)
+    assert aug(x, torch.from_numpy(ei).cuda(), None) is g      # cached like the reference
+
+
 def test_large_graph_properties(ops):
     """Size-independent checks at a size the oracle is not run for (invariants of a16-a19)."""
     from rlap_amd import graphs
