@@ -279,8 +279,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
 
     if (h->timing) HIPCHK(hipEventRecord(h->ev[1], s));
     // ---------------- elimination ----------------
-    hipLaunchKernelGGL(k_eliminate_batch, dim3((unsigned)G), dim3(1024), 0, s, A, h->gd_d.as<GraphDesc>(), ES,
-                       h->batch_pos.as<int32_t>(), h->tcount.as<int32_t>());
+    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>(), h->tcount.as<int32_t>());
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
     HIPCHK(hipMemcpyAsync(gd.data(), h->gd_d.p, sizeof(GraphDesc) * G, hipMemcpyDeviceToHost, s));
@@ -288,9 +287,9 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     if (ES.prof) {
         long long pr[24];
         HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
-        const char* names[15] = {"P0 select", "P1c4 permute", "P1b depend", "P2+P3 offsets+sample", "P4 replay", "single path", "P5b slots+contended", "moves sort", "pushes", "P1ab meta+loads", "P5a loads+scan+bump", "P5c rewire stores", "P1c1 rank", "P1c2 write", "P1c3 order-index"};
+        const char* names[19] = {"P0 select", "P1c4 permute", "P1b depend", "P2+P3 offsets+sample", "P4 replay", "single path", "P5b slots+contended", "moves sort", "pushes", "P1ab meta+loads", "P5a loads+scan+bump", "P5c rewire stores", "P1c1 rank", "P1c2d sync after R2", "P1c3 order-index", "P1c2a write pass (wave0)", "P1c2b sync after write", "P1c2c R2 pass (wave0)", "empty (cost of one stamp)"};
         std::fprintf(stderr, "[rlap phase profile] rounds=%lld singles=%lld (100 MHz ticks); shader clock over the kernel: %.0f MHz\n", pr[22], pr[23], pr[21] > 0 ? 100.0 * (double)pr[20] / (double)pr[21] : 0.0);
-        for (int k = 0; k < 15; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
+        for (int k = 0; k < 19; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
     }
     for (int64_t g = 0; g < G; ++g) {
         if (gd[g].status) {

@@ -65,11 +65,17 @@ RLAP_HD uint64_t keyed_order_key(uint64_t base, int64_t nbr) { return mix64(base
 // segment descending.
 // ---------------------------------------------------------------------------
 constexpr int CHUNK0 = 8;
-RLAP_HD int chunk_of(int a) {  // chunk index of appended index a
-    unsigned q = (unsigned)a / CHUNK0 + 1u;
+RLAP_HD int ilog2_u32(unsigned q) {  // floor(log2(q)), q >= 1
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 31 - __clz((int)q);
+#else
     int c = 0;
     while (q > 1u) { q >>= 1; ++c; }
     return c;
+#endif
+}
+RLAP_HD int chunk_of(int a) {  // chunk index of appended index a
+    return ilog2_u32((unsigned)a / CHUNK0 + 1u);
 }
 RLAP_HD int chunk_start(int c) { return CHUNK0 * ((1 << c) - 1); }
 RLAP_HD int chunk_cap(int c) { return CHUNK0 << c; }
@@ -390,12 +396,7 @@ RLAP_HD int32_t serial_gather(const Arrays& A, int32_t v, const ColBuf& B, int32
 // was popped (pqpos != id); stale entries are dropped when they reach the top.
 constexpr int BCH0 = 16;   // capacity of a bucket stack's first chunk
 constexpr int BDIR = 26;   // directory entries per bucket (covers 2^30 entries)
-RLAP_HD int bs_chunk_of(int a) {
-    unsigned q = (unsigned)a / BCH0 + 1u;
-    int c = 0;
-    while (q > 1u) { q >>= 1; ++c; }
-    return c;
-}
+RLAP_HD int bs_chunk_of(int a) { return ilog2_u32((unsigned)a / BCH0 + 1u); }
 RLAP_HD int bs_chunk_start(int c) { return BCH0 * ((1 << c) - 1); }
 RLAP_HD int bs_chunk_cap(int c) { return BCH0 << c; }
 // pool slot of entry `a` of bucket `b` (global bucket index); chunk must exist
@@ -633,7 +634,7 @@ struct Ent {
     int32_t nbr;
     int32_t twin;
 };
-enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8, CF_TIE = 16, CF_NEQ = 32 };
+enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8, CF_TIE = 16, CF_NEQ = 32, CF_READY = 64 };
 enum { TF_CONTENDED = 1 };
 
 struct Cand {

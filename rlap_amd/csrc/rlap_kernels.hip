@@ -604,7 +604,7 @@ union ElimShared {
 };
 
 // exclusive block scan over NT threads; returns exclusive prefix, *total = sum
-__device__ __forceinline__ int block_excl_scan(int val, int* scratch, int* total) {
+__device__ __noinline__ int block_excl_scan(int val, int* scratch, int* total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int incl = val;
     for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -663,18 +663,27 @@ __device__ __forceinline__ void slots_into_target(const Arrays& A, const Cand& C
     }
 }
 
+__device__ __noinline__ void cand_order_index_call(const Arrays& A, Cand& C) { cand_order_index(A, C); }
+
 __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G, const ElimScratch& S, int32_t v0, int64_t e1) {
     ColBuf Bf = S.colbuf(G.scr_base);
     int rc = serial_eliminate(A, G, Bf, G.scr_cap, v0, e1);
     if (rc) G.status = rc;
 }
 
-__global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __restrict__ gd, ElimScratch S,
-                                                         int32_t* __restrict__ batch_pos, int32_t* __restrict__ tcount) {
+// Specialised on (o_v, o_n): the mode tests fold away, which keeps the round loop's code (executed once
+// per round by every wave) small enough for the instruction cache.
+template <int OV, int ON>
+__global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
+                                                           int32_t* __restrict__ batch_pos, int32_t* __restrict__ tcount) {
+    Arrays A = A_in;
+    A.o_v = OV;
+    A.o_n = ON;
     __shared__ ElimShared sh;
     __shared__ GraphDesc G;
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status;
     __shared__ uint8_t s_eqperm[16][32];   // std::sort's permutation of n = 17..32 all-equal keys
+    __shared__ uint8_t s_eqinv[16][32];    // its inverse: final position of the entry with id-rank r
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
@@ -686,6 +695,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
         KIArr arr; arr.e = C.e; arr.ix = C.ksel;
         gs_std_sort_small<KI>(arr, nn, KILess());
         for (int q = 0; q < 32; ++q) s_eqperm[tid][q] = q < nn ? C.ksel[q] : (uint8_t)q;
+        for (int q = 0; q < 32; ++q) s_eqinv[tid][s_eqperm[tid][q]] = (uint8_t)q;
     }
     __syncthreads();
     const int32_t n = G.n;
@@ -798,6 +808,45 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                     lv[k] = A.e_val[sl]; ln[k] = A.e_nbr[sl]; lt[k] = A.e_twin[sl];
                 }
             }
+            // Shortcut for the common column: no appended entries, CSR segment still sorted, all live
+            // weights equal, weight order.  Read backwards it is in descending id, so the id rank is a
+            // popcount of the live mask; std::sort of all-equal keys is the identity up to 16 entries and a
+            // fixed permutation above: every entry goes straight to its final position.
+            const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
+            bool ready[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t idx = k * NT + tid;
+                const int32_t i = idx / BCAP, e = idx % BCAP;
+                const int hb = lane & 32;
+                const bool live = la[k] && lv[k] > 0;
+                const uint32_t half = (uint32_t)(__ballot(live) >> hb);
+                const int32_t nxt = __shfl_down(ln[k], 1);
+                const bool cand_ok = (i < nc) && !(L.cand[i].flags & CF_BIG);
+                const int32_t ext = cand_ok ? L.cand[i].ext : 0;
+                const bool unsorted = la[k] && (e + 1 < ext) && !(ln[k] > nxt);
+                const uint32_t hbad = (uint32_t)(__ballot(unsorted) >> hb);
+                const int f = half ? __builtin_ctz(half) : 0;
+                const double w0 = __shfl(lv[k], hb + f);
+                const uint32_t hdw = (uint32_t)(__ballot(live && lv[k] != w0) >> hb);
+                ready[k] = cand_ok && !keyed && L.cand[i].acnt == 0 && hbad == 0 && hdw == 0;
+                if (ready[k]) {
+                    Cand& C = L.cand[i];
+                    const int32_t m = __popc(half);
+                    if (live) {
+                        const int32_t r = __popc(half & ~((2u << e) - 1u));
+                        const int32_t pos = (m <= 16) ? r : (int32_t)s_eqinv[m - 17][r];
+                        Ent& E = C.e[pos];
+                        E.val = lv[k]; E.nbr = ln[k]; E.twin = lt[k]; E.aux = 0;
+                    }
+                    if (e == 0) {
+                        C.m = m;
+                        C.ndraw = m > 1 ? m - 1 : 0;
+                        C.flags |= CF_READY;
+                    }
+                    la[k] = false;   // nothing left to do for this slot
+                }
+            }
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 if (la[k]) {
@@ -815,6 +864,8 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             int32_t rk[PASSES];
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
+                rk[k] = -1;
+                if (__ballot(la[k]) == 0ull) continue;   // wave-uniform: nothing left in this pass for this wave
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, e = idx % BCAP;
                 const bool live = la[k] && lv[k] > 0;
@@ -825,7 +876,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                 const bool unsorted = la[k] && (i < nc) && (e + 1 < L.cand[i].ext) && !(ln[k] > nxt);
                 const uint32_t hbad = (uint32_t)(__ballot(unsorted) >> (lane & 32));
                 rk[k] = -1;
-                if (i < nc && L.cand[i].ext > 0) {
+                if (!ready[k] && i < nc && L.cand[i].ext > 0) {
                     Cand& C = L.cand[i];
                     if (C.acnt == 0 && hbad == 0) {
                         if (live) rk[k] = __popc(half & ~((2u << e) - 1u));
@@ -849,9 +900,9 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             }
             __syncthreads();
             PHASE_STAMP(12);
-            const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
+                if (__ballot(rk[k] >= 0) == 0ull) continue;
                 if (rk[k] >= 0) {
                     const int32_t idx = k * NT + tid;
                     Cand& C = L.cand[idx / BCAP];
@@ -860,7 +911,10 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                     E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v, 0), ln[k]) : lv[k];
                 }
             }
+            PHASE_STAMP(15);
+            PHASE_STAMP(18);
             __syncthreads();
+            PHASE_STAMP(16);
             // o_n order with std::sort semantics under ties.  All-equal keys (unit weights): identity for
             // m <= 16, a precomputed permutation above.  Otherwise a stable rank is exact for m <= 16
             // (pure insertion sort) and whenever the keys are distinct; the rest is emulated by one thread.
@@ -871,7 +925,8 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                 r2[k] = -1;
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, j = idx % BCAP;
-                const bool valid = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP)) && (j < L.cand[i].m);
+                const bool valid = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP | CF_READY)) && (j < L.cand[i].m);
+                if (__ballot(valid) == 0ull) continue;
                 double kme = 0, k0 = 0;
                 if (valid) { kme = L.cand[i].e[j].aux; k0 = L.cand[i].e[0].aux; }
                 const uint32_t hdiff = (uint32_t)(__ballot(valid && kme != k0) >> (lane & 32));
@@ -895,10 +950,12 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                     }
                 }
             }
+            PHASE_STAMP(17);
             __syncthreads();
             PHASE_STAMP(13);
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
+                if (__ballot(r2[k] >= 0) == 0ull) continue;
                 if (r2[k] >= 0) {
                     const int32_t idx = k * NT + tid;
                     Cand& C = L.cand[idx / BCAP];
@@ -907,9 +964,9 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             }
             if (tid < nc) {
                 Cand& C = L.cand[tid];
-                if (!(C.flags & (CF_BIG | CF_DUP))) {
+                if (!(C.flags & (CF_BIG | CF_DUP | CF_READY))) {
                     const int32_t m = C.m;
-                    if (m > 16 && (C.flags & CF_TIE) && (C.flags & CF_NEQ)) cand_order_index(A, C);
+                    if (m > 16 && (C.flags & CF_TIE) && (C.flags & CF_NEQ)) { Arrays A3 = A; cand_order_index_call(A3, C); }
                     C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
                 }
             }
@@ -921,13 +978,15 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, j = idx % BCAP;
-                pa[k] = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP)) && (j < L.cand[i].m);
+                pa[k] = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP | CF_READY)) && (j < L.cand[i].m);
                 pv[k] = 0; pn[k] = 0; pt[k] = 0;
+                if (__ballot(pa[k]) == 0ull) continue;
                 if (pa[k]) { const Ent& Sx = L.cand[i].e[L.cand[i].ksel[j]]; pv[k] = Sx.val; pn[k] = Sx.nbr; pt[k] = Sx.twin; }
             }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
+                if (__ballot(pa[k]) == 0ull) continue;
                 if (pa[k]) {
                     const int32_t idx = k * NT + tid;
                     Ent& E = L.cand[idx / BCAP].e[idx % BCAP];
@@ -939,10 +998,12 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
         PHASE_STAMP(1);
         // ================= P1b: first candidate that depends on an earlier one =================
         if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);
-        for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+        #pragma unroll 1
+        for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
             const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
-            if (i >= nc) continue;
-            if (j < L.cand[i].m) {
+            const bool act = (i < nc) && (j < L.cand[i].m);
+            if (__ballot(act) == 0ull) continue;
+            if (act) {
                 int32_t bp = batch_pos[L.cand[i].e[j].nbr];
                 if (bp >= 0 && bp < i) atomicMin(&s_pmax, i);
             }
@@ -963,7 +1024,8 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             }
             __syncthreads();
             if (A.o_v != OV_COARSEN) {
-                for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+                #pragma unroll 1
+                for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
                     const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                     if (i >= Pmax) continue;
                     if (j < L.cand[i].m - 1) cand_pick(A, L.cand[i], j);
@@ -973,13 +1035,15 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             __syncthreads();
             PHASE_STAMP(3);
             // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
-            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+            #pragma unroll 1
+            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                 if (i >= Pmax) continue;
                 if (j < L.cand[i].m) atomicAdd(&tcount[L.cand[i].e[j].nbr], 1);
             }
             __syncthreads();
-            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+            #pragma unroll 1
+            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                 if (i >= Pmax) continue;
                 Cand& C = L.cand[i];
@@ -1047,7 +1111,8 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
                 if (pre) atomicMin(&s_p, tid + 1);
             }
             // tcount back to zero for the next round
-            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs: waves whose candidates are short skip later passes
+            #pragma unroll 1
+            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                 if (i >= Pmax) continue;
                 if (j < L.cand[i].m) tcount[L.cand[i].e[j].nbr] = 0;
@@ -1122,7 +1187,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
             }
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                if (actk[k] && Rk[k].c > 0) {
+                if (__ballot(actk[k] && Rk[k].c > 0) != 0ull && actk[k] && Rk[k].c > 0) {
                     for (int32_t t = 0; t < (int32_t)Rk[k].c; ++t) {
                         int32_t a = a0k[k] + t;
                         int c = chunk_of(a);
@@ -1149,6 +1214,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                if (__ballot(actk[k]) == 0ull) continue;
                 if (actk[k] && Rk[k].c > 0 && status == 0) {
                     const Cand& C = L.cand[i];
                     int32_t a = a0k[k], chunk = chk[k];
@@ -1381,6 +1447,15 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch(Arrays A, GraphDesc* __r
         if (S.prof && g == 0) { for (int q = 0; q < 20; ++q) S.prof[q] = s_prof[q]; S.prof[20] = clock64() - clk0; S.prof[21] = wall_clock64() - wall0; S.prof[22] = rounds; S.prof[23] = singles; }
         gd[g] = G;
     }
+}
+
+void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
+                            int32_t* batch_pos, int32_t* tcount) {
+#define RLAP_CASE(OV, ON) if (o_v == OV && o_n == ON) { hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON>), dim3(G), dim3(NT), 0, stream, A, gd, S, batch_pos, tcount); return; }
+    RLAP_CASE(OV_RANDOM, ON_ASC) RLAP_CASE(OV_RANDOM, ON_DESC) RLAP_CASE(OV_RANDOM, ON_RANDOM)
+    RLAP_CASE(OV_DEGREE, ON_ASC) RLAP_CASE(OV_DEGREE, ON_DESC) RLAP_CASE(OV_DEGREE, ON_RANDOM)
+    RLAP_CASE(OV_COARSEN, ON_ASC) RLAP_CASE(OV_COARSEN, ON_DESC) RLAP_CASE(OV_COARSEN, ON_RANDOM)
+#undef RLAP_CASE
 }
 
 // ---------------------------------------------------------------------------
