@@ -15,7 +15,7 @@ _lib = None
 EXPORTS = [
     "rlap_create", "rlap_destroy", "rlap_set_stream", "rlap_set_timing", "rlap_status_string",
     "rlap_identity", "rlap_unpack_edge_info", "rlap_approx_chol", "rlap_approx_chol_batched",
-    "rlap_rng_uniforms", "rlap_util_ba_graph",
+    "rlap_rng_uniforms", "rlap_util_ba_graph", "rlap_debug_wave_sort",
 ]
 
 
@@ -64,6 +64,8 @@ def load():
                                              ctypes.POINTER(Stats)]
     lib.rlap_rng_uniforms.restype = ci
     lib.rlap_rng_uniforms.argtypes = [vp, i64, vp]
+    lib.rlap_debug_wave_sort.restype = ci
+    lib.rlap_debug_wave_sort.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]
     lib.rlap_util_ba_graph.restype = i64
     lib.rlap_util_ba_graph.argtypes = [i64, i64, u64, vp, vp]
     _lib = lib

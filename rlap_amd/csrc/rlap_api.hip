@@ -58,7 +58,7 @@ struct rlap_handle_s {
     int64_t rng_len = 0;
     DevBuf scr_rec, scr_i32, scr_f64;
     // output
-    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, counters, biglist;
+    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, counters, biglist, biglists;
     // growth factors kept across calls
     double pool_factor = 1.0;
     double log_factor = 2.0;
@@ -354,8 +354,10 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIGCAP * 16));
             attr_set = true;
         }
+        ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
         hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s, A, order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
-                           h->biglist.as<int32_t>(), bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1);
+                           h->biglist.as<int32_t>(), bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1,
+                           h->biglists.as<uint16_t>());
         HIPCHK(hipGetLastError());
     }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[4], s));
@@ -420,7 +422,7 @@ int rlap_destroy(rlap_handle h) {
                       &h->deg, &h->colptr, &h->slot_col, &h->gcol, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
                       &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->tcount, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
-                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters, &h->biglist};
+                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters, &h->biglist, &h->biglists};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     delete h;
@@ -512,6 +514,15 @@ int rlap_rng_uniforms(rlap_handle h, int64_t count, double* d_out) {
     int rc = ensure_rng(h, count);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d_out, h->rng.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return RLAP_OK;
+}
+
+int rlap_debug_wave_sort(rlap_handle h, const double* d_keys, const int32_t* d_offs, int32_t narr, int32_t desc, int32_t* d_perm_out) {
+    if (!h || narr < 0) return RLAP_E_BAD_ARG;
+    if (narr == 0) return RLAP_OK;
+    hipLaunchKernelGGL(k_debug_wave_sort, dim3((unsigned)std::min<int32_t>(narr, 2048)), dim3(64), 0, h->stream, d_keys, d_offs, narr, desc, d_perm_out);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return RLAP_OK;
 }

@@ -1499,6 +1499,179 @@ __global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __re
     ext[i] = (colptr[v + 1] - colptr[v]) + app_cnt[v];
 }
 
+// ---------------------------------------------------------------------------
+// Wave-parallel restatement of libstdc++'s std::sort (same permutation under ties as
+// rlap_core.h::gs_std_sort, which is the sequential restatement).  One wave, data in LDS.
+//   * introsort loop: the unguarded Hoare partition is done by the whole wave.  The up-scan stops at
+//     the positions with !(x < pivot), the down-scan at those with !(pivot < x); the t-th up-stop is
+//     swapped with the t-th down-stop while it lies to its left, and swapped elements are never
+//     looked at again, so both stop lists can be taken from the array as it is before the swaps.
+//     With k swaps, the cut is min(u_k, d_{k-1}).
+//   * final insertion sort == independent stable sorts of the <=16-element segments the loop leaves
+//     (everything left of a cut is <= everything right of it), one lane per segment.
+// Scratch per wave: two uint16 lists of n entries, n bits of segment marks, a small segment stack.
+// ---------------------------------------------------------------------------
+struct WaveSortScratch {
+    uint16_t ulist[SCAP + 2];
+    uint16_t dlist[SCAP + 2];
+    uint32_t segmark[(SCAP + 31) / 32 + 1];
+    int32_t stk[3 * 48];
+};
+
+struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; };
+
+template <class T, class Less>
+__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane) {
+    struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
+    if (n < 2) return;
+    const uint64_t lt = lanemask_lt(lane);
+    for (int q = lane; q < (n + 31) / 32 + 1; q += 64) W.segmark[q] = 0u;
+    WAVE_SYNC();
+    if (n <= 16) {
+        if (lane == 0) gs_insertion_sort<T>(a, n, less);
+        WAVE_SYNC();
+        return;
+    }
+    int depth0 = 0;
+    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+    depth0 *= 2;
+    int sp = 0;
+    if (lane == 0) { W.stk[0] = 0; W.stk[1] = n; W.stk[2] = depth0; }
+    sp = 1;
+    WAVE_SYNC();
+    while (sp > 0) {
+        --sp;
+        int first = W.stk[3 * sp], last = W.stk[3 * sp + 1], depth = W.stk[3 * sp + 2];
+        bool heap_sorted = false;
+        while (last - first > 16) {
+            if (depth == 0) {
+                if (lane == 0) gs_heap_sort<T>(a, first, last, less);
+                WAVE_SYNC();
+                heap_sorted = true;
+                break;
+            }
+            --depth;
+            // __move_median_to_first(first, first+1, mid, last-1), by one lane
+            if (lane == 0) {
+                int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                int pick;
+                if (less(a[ia], a[ib])) {
+                    if (less(a[ib], a[ic])) pick = ib;
+                    else if (less(a[ia], a[ic])) pick = ic;
+                    else pick = ia;
+                } else if (less(a[ia], a[ic])) pick = ia;
+                else if (less(a[ib], a[ic])) pick = ic;
+                else pick = ib;
+                T t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            WAVE_SYNC();
+            const T pv = a[first];
+            // stop lists of the two scans over [first+1, last)
+            int nu = 0, nd = 0;
+            for (int p0 = first + 1; p0 < last; p0 += 64) {
+                int p = p0 + lane;
+                bool stop = (p < last) && !less(a[p], pv);
+                uint64_t mk = __ballot(stop);
+                if (stop) W.ulist[nu + popc64(mk & lt)] = (uint16_t)p;
+                nu += popc64(mk);
+            }
+            for (int p0 = last - 1; p0 > first; p0 -= 64) {
+                int p = p0 - lane;
+                bool stop = (p > first) && !less(pv, a[p]);
+                uint64_t mk = __ballot(stop);
+                if (stop) W.dlist[nd + popc64(mk & lt)] = (uint16_t)p;
+                nd += popc64(mk);
+            }
+            if (lane == 0) W.dlist[nd] = (uint16_t)first;   // the pivot itself stops the down-scan
+            WAVE_SYNC();
+            // number of swaps: pairs (u_t, d_t) with u_t < d_t form a prefix
+            int k = 0;
+            {
+                const int tmax = nu < nd ? nu : nd;
+                bool open = true;
+                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
+                    int t = t0 + lane;
+                    bool ok = (t < tmax) && (W.ulist[t] < W.dlist[t]);
+                    uint64_t mk = __ballot(ok);
+                    // ok is monotone (true...true,false...): count the leading run
+                    uint64_t inv = ~mk;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    k += run;
+                    open = (run == 64);
+                }
+            }
+            T xu, xd;
+            for (int t0 = 0; t0 < k; t0 += 64) {
+                int t = t0 + lane;
+                if (t < k) { xu = a[W.ulist[t]]; xd = a[W.dlist[t]]; }
+                WAVE_SYNC();
+                if (t < k) { a[W.ulist[t]] = xd; a[W.dlist[t]] = xu; }
+                WAVE_SYNC();
+            }
+            int cut;
+            {
+                int cu = (k < nu) ? (int)W.ulist[k] : 0x7FFFFFFF;
+                int cd = (k > 0) ? (int)W.dlist[k - 1] : 0x7FFFFFFF;
+                cut = cu < cd ? cu : cd;
+            }
+            WAVE_SYNC();
+            // recurse on [cut,last), continue with [first,cut)
+            if (last - cut > 16) {
+                if (lane == 0) { W.stk[3 * sp] = cut; W.stk[3 * sp + 1] = last; W.stk[3 * sp + 2] = depth; }
+                ++sp;
+            } else if (lane == 0) {
+                atomicOr(&W.segmark[cut >> 5], 1u << (cut & 31));
+            }
+            WAVE_SYNC();
+            last = cut;
+        }
+        if (lane == 0) atomicOr(&W.segmark[first >> 5], 1u << (first & 31));
+        (void)heap_sorted;
+        WAVE_SYNC();
+    }
+    // final insertion sort: lane l takes the segments that start in the 32-position words l, l+64, ...
+    for (int w0 = lane; w0 * 32 < n; w0 += 64) {
+        uint32_t bits = W.segmark[w0];
+        while (bits) {
+            const int s0 = w0 * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            int e0 = n;   // end = next mark after s0, or n
+            if (bits) e0 = w0 * 32 + __builtin_ctz(bits);
+            else {
+                for (int w1 = w0 + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } }
+            }
+            for (int i = s0 + 1; i < e0; ++i) {
+                T v = a[i];
+                int j = i - 1;
+                while (j >= s0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
+                a[j + 1] = v;
+            }
+        }
+    }
+    WAVE_SYNC();
+}
+
+struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key < y.key; } };
+struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
+
+// test hook: one wave sorts one array of doubles, returns the permutation (tests/test_gpu_parity.py)
+__global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict__ keys, const int32_t* __restrict__ offs, int32_t narr,
+                                                        int32_t desc, int32_t* __restrict__ perm_out) {
+    __shared__ SRec rec[SCAP];
+    __shared__ WaveSortScratch W;
+    const int lane = lane_id();
+    for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
+        const int32_t o = offs[arr], n = offs[arr + 1] - o;
+        for (int q = lane; q < n; q += 64) { rec[q].key = keys[o + q]; rec[q].idx = q; rec[q].aux = 0; }
+        __syncthreads();
+        WaveSortPtrs WP = {W.ulist, W.dlist, W.segmark, W.stk};
+        if (desc) wave_std_sort<SRec>(rec, n, SRecGreaterKey(), WP, lane); else wave_std_sort<SRec>(rec, n, SRecLessKey(), WP, lane);
+        __syncthreads();
+        for (int q = lane; q < n; q += 64) perm_out[o + q] = rec[q].idx;
+        __syncthreads();
+    }
+}
+
 struct ScLds {
     SRec rec[SCAP];
     double a_val[SCAP];
@@ -1539,6 +1712,8 @@ __global__ __launch_bounds__(64) void k_sc_merge(Arrays A, const GraphDesc* __re
                                                  double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out, ScScratch SS,
                                                  unsigned long long* __restrict__ live_total) {
     __shared__ ScLds L;
+    __shared__ WaveSortScratch WS;
+    const WaveSortPtrs WP = {WS.ulist, WS.dlist, WS.segmark, WS.stk};
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     for (int32_t i = blockIdx.x; i < S; i += gridDim.x) {
@@ -1603,10 +1778,9 @@ __global__ __launch_bounds__(64) void k_sc_merge(Arrays A, const GraphDesc* __re
             bool done = sc_rank_sort<false>(L, len0, [&](int q) { return (double)L.a_nbr[q]; }, lane);
             __syncthreads();
             if (!done) {
-                if (lane == 0) {
-                    for (int q = 0; q < len0; ++q) { L.rec[q].key = (double)L.a_nbr[q]; L.rec[q].idx = q; }
-                    std_sort_emul<false>(L.rec, len0);
-                }
+                for (int q = lane; q < len0; q += 64) { L.rec[q].key = (double)L.a_nbr[q]; L.rec[q].idx = q; }
+                __syncthreads();
+                wave_std_sort<SRec>(L.rec, len0, SRecLessKey(), WP, lane);
                 __syncthreads();
             }
         }
@@ -1639,30 +1813,27 @@ __global__ __launch_bounds__(64) void k_sc_merge(Arrays A, const GraphDesc* __re
                 done = sc_rank_sort<false>(L, m, [&](int q) { return keyed_order_dkey(kb, L.b_nbr[q]); }, lane);
                 __syncthreads();
                 if (!done) {
-                    if (lane == 0) {
-                        for (int q = 0; q < m; ++q) { L.rec[q].key = keyed_order_dkey(kb, L.b_nbr[q]); L.rec[q].idx = q; }
-                        std_sort_emul<false>(L.rec, m);
-                    }
+                    for (int q = lane; q < m; q += 64) { L.rec[q].key = keyed_order_dkey(kb, L.b_nbr[q]); L.rec[q].idx = q; }
+                    __syncthreads();
+                    wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
                     __syncthreads();
                 }
             } else if (A.o_n == ON_ASC) {
                 done = sc_rank_sort<false>(L, m, [&](int q) { return L.b_val[q]; }, lane);
                 __syncthreads();
                 if (!done) {
-                    if (lane == 0) {
-                        for (int q = 0; q < m; ++q) { L.rec[q].key = L.b_val[q]; L.rec[q].idx = q; }
-                        std_sort_emul<false>(L.rec, m);
-                    }
+                    for (int q = lane; q < m; q += 64) { L.rec[q].key = L.b_val[q]; L.rec[q].idx = q; }
+                    __syncthreads();
+                    wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
                     __syncthreads();
                 }
             } else {
                 done = sc_rank_sort<true>(L, m, [&](int q) { return L.b_val[q]; }, lane);
                 __syncthreads();
                 if (!done) {
-                    if (lane == 0) {
-                        for (int q = 0; q < m; ++q) { L.rec[q].key = L.b_val[q]; L.rec[q].idx = q; }
-                        std_sort_emul<true>(L.rec, m);
-                    }
+                    for (int q = lane; q < m; q += 64) { L.rec[q].key = L.b_val[q]; L.rec[q].idx = q; }
+                    __syncthreads();
+                    wave_std_sort<SRec>(L.rec, m, SRecGreaterKey(), WP, lane);
                     __syncthreads();
                 }
             }
@@ -1696,9 +1867,13 @@ __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* _
                                                      const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
                                                      const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
                                                      double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
-                                                     unsigned long long* __restrict__ live_total) {
+                                                     unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists) {
     extern __shared__ Rec2 R[];   // BIGCAP records
     __shared__ int32_t s_m;
+    __shared__ uint32_t s_segmark[BIGCAP / 32 + 2];
+    __shared__ int32_t s_stk[3 * 48];
+    // stop lists of the partition emulation: global scratch, one region per workgroup
+    const WaveSortPtrs WP = {lists + (size_t)blockIdx.x * 2 * (BIGCAP + 2), lists + (size_t)blockIdx.x * 2 * (BIGCAP + 2) + (BIGCAP + 2), s_segmark, s_stk};
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     const int32_t nbig = *count;
@@ -1802,16 +1977,17 @@ __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* _
             }
             __syncthreads();
         }
+        if (exact_needed) { wave_std_sort<Rec2>(R, len0, Rec2LessA(), WP, lane); __syncthreads(); }
         if (lane == 0) {
-            if (exact_needed) gs_std_sort<Rec2>(R, len0, Rec2LessA());
             int32_t m = 0;
             for (int32_t q = 0; q < len0; ++q) {               // :317-329
                 if (m == 0 || R[q].a != R[m - 1].a) { R[m] = R[q]; ++m; }
                 else R[m - 1].b += R[q].b;
             }
-            if (A.o_n == ON_ASC) gs_std_sort<Rec2>(R, m, Rec2LessB()); else gs_std_sort<Rec2>(R, m, Rec2GreaterB());   // :331-338
             s_m = m;
         }
+        __syncthreads();
+        if (A.o_n == ON_ASC) wave_std_sort<Rec2>(R, s_m, Rec2LessB(), WP, lane); else wave_std_sort<Rec2>(R, s_m, Rec2GreaterB(), WP, lane);   // :331-338
         __syncthreads();
         const int32_t m = s_m;
         for (int32_t j = lane; j < m; j += 64) { tmp_nbr[toff + j] = (int32_t)R[j].a; tmp_val[toff + j] = R[j].b; }

@@ -49,6 +49,44 @@ def test_rng_table_matches_mt19937_64(ops):
         assert struct.unpack("<Q", struct.pack("<d", float(u[i])))[0] == int(b, 16)
 
 
+def test_wave_parallel_std_sort_matches_libstdcxx(ops):
+    """The wave-parallel emulation (parallel Hoare partition + per-segment insertion) must give
+    libstdc++'s permutation, ties included."""
+    import ctypes
+    from rlap_amd import _lib
+    rng = np.random.RandomState(0)
+    arrays = []
+    for trial in range(1500):
+        n = int(rng.choice([1, 2, 15, 16, 17, 18, 31, 32, 33, 40, 63, 64, 65, 100, 127, 128, 129, 257, 400, 512]))
+        kind = trial % 6
+        if kind == 0:
+            k = np.ones(n)
+        elif kind == 1:
+            k = rng.randint(0, 3, size=n).astype(float)
+        elif kind == 2:
+            k = rng.rand(n)
+        elif kind == 3:
+            k = np.sort(rng.randint(0, n // 4 + 1, size=n)).astype(float)
+        elif kind == 4:
+            k = np.sort(rng.randint(0, n // 4 + 1, size=n))[::-1].astype(float)
+        else:
+            k = np.concatenate([np.ones(n // 2), rng.rand(n - n // 2)])[rng.permutation(n)]
+        arrays.append(k)
+    offs = np.zeros(len(arrays) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(a) for a in arrays])
+    keys = torch.from_numpy(np.concatenate(arrays)).cuda()
+    offs_t = torch.from_numpy(offs).cuda()
+    lib, h = ops._handle(torch.device("cuda", 0))
+    for desc in (0, 1):
+        out = torch.empty(int(offs[-1]), dtype=torch.int32, device="cuda")
+        rc = lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr())
+        assert rc == 0
+        got = out.cpu().numpy()
+        for a_i, k in enumerate(arrays):
+            exp = oracle.stdsort_perm(k, bool(desc))
+            assert np.array_equal(got[offs[a_i]:offs[a_i + 1]], exp), (a_i, len(k), desc)
+
+
 def test_identity_round_trip(ops):
     # reference tests/test_rlap.py:12-20
     for _ in range(3):
