@@ -338,17 +338,16 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = bigcap; SS.top = counters + 0;
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
     if (S > 0) {
-        unsigned grid = (unsigned)std::min<int64_t>(S, 256 * 7 * 4);
-        hipLaunchKernelGGL(k_sc_merge, dim3(grid), dim3(64), 0, s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(),
-                           h->tmp_off.as<int64_t>(), (int32_t)S, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1);
+        ENSURE(h->biglist, 4 * 4 * (S + 1));
+        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 4 ints: tiers 0..3
+        launch_sc_merge(s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
+                        h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1, h->biglist.as<int32_t>(), tiercounts);
         HIPCHK(hipGetLastError());
     }
     if (S > 0) {
         // long columns: whole column in LDS, one single-wave workgroup each
-        ENSURE(h->biglist, 4 * (S + 1));
-        int32_t* bigcount = reinterpret_cast<int32_t*>(counters + 3);
-        const int keyed = (c.o_n == ON_RANDOM || c.o_v == OV_COARSEN) ? 1 : 0;
-        hipLaunchKernelGGL(k_sc_biglist, dim3(nblk(S, 256)), dim3(256), 0, s, h->ext.as<int32_t>(), (int32_t)S, keyed, h->biglist.as<int32_t>(), bigcount);
+        int32_t* bigcount = reinterpret_cast<int32_t*>(counters + 4) + 3;
+        int32_t* biglist_ptr = h->biglist.as<int32_t>() + 3 * (size_t)S;
         static bool attr_set = false;
         if (!attr_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIGCAP * 16));
@@ -356,7 +355,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         }
         ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
         hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s, A, order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
-                           h->biglist.as<int32_t>(), bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1,
+                           biglist_ptr, bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1,
                            h->biglists.as<uint16_t>());
         HIPCHK(hipGetLastError());
     }

@@ -70,9 +70,9 @@ __global__ void k_sc_keys(const int32_t* key, const int32_t* pqpos, const int32_
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,
                                 uint32_t* order);
 __global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const int32_t* app_cnt, int32_t S, int32_t* ext);
-__global__ void k_sc_merge(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
-                           const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, ScScratch SS,
-                           unsigned long long* live_total);
+void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
+                     const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
+                     unsigned long long* live_total, int32_t* lists, int32_t* counts);
 __global__ void k_debug_wave_sort(const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out);
 __global__ void k_sc_biglist(const int32_t* ext, int32_t S, int32_t keyed, int32_t* list, int32_t* count);
 __global__ void k_sc_merge_big(Arrays A, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,

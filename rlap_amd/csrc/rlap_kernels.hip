@@ -1511,12 +1511,14 @@ __global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __re
 //     (everything left of a cut is <= everything right of it), one lane per segment.
 // Scratch per wave: two uint16 lists of n entries, n bits of segment marks, a small segment stack.
 // ---------------------------------------------------------------------------
-struct WaveSortScratch {
-    uint16_t ulist[SCAP + 2];
-    uint16_t dlist[SCAP + 2];
-    uint32_t segmark[(SCAP + 31) / 32 + 1];
+template <int CAP>
+struct WaveSortScratchT {
+    uint16_t ulist[CAP + 2];
+    uint16_t dlist[CAP + 2];
+    uint32_t segmark[(CAP + 31) / 32 + 1];
     int32_t stk[3 * 48];
 };
+typedef WaveSortScratchT<SCAP> WaveSortScratch;
 
 struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; };
 
@@ -1672,17 +1674,18 @@ __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict
     }
 }
 
-struct ScLds {
-    SRec rec[SCAP];
-    double a_val[SCAP];
-    double b_val[SCAP];
-    int32_t a_nbr[SCAP];
-    int32_t b_nbr[SCAP];
-    int32_t rank[SCAP];
+template <int CAP>
+struct ScLdsT {
+    SRec rec[CAP];
+    double a_val[CAP];
+    double b_val[CAP];
+    int32_t a_nbr[CAP];
+    int32_t b_nbr[CAP];
+    int32_t rank[CAP];
 };
 
-template <bool GREATER, class KeyF>
-__device__ __forceinline__ bool sc_rank_sort(ScLds& L, int cnt, KeyF keyf, int lane) {
+template <bool GREATER, class LDS, class KeyF>
+__device__ __forceinline__ bool sc_rank_sort(LDS& L, int cnt, KeyF keyf, int lane) {
     bool dup = false;
     for (int i = lane; i < cnt; i += 64) {
         double ki = keyf(i);
@@ -1706,17 +1709,24 @@ __device__ __forceinline__ bool sc_rank_sort(ScLds& L, int cnt, KeyF keyf, int l
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_sc_merge(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
-                                                 const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
-                                                 const int64_t* __restrict__ tmp_off, int32_t S, int32_t* __restrict__ tmp_nbr,
-                                                 double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out, ScScratch SS,
-                                                 unsigned long long* __restrict__ live_total) {
-    __shared__ ScLds L;
-    __shared__ WaveSortScratch WS;
+// CAP = LDS capacity per column; columns with extent in (LO, CAP] are taken, the others left to the other
+// instantiation / the long-column kernel.  The small instantiation (CAP 64) keeps ~30 waves per CU resident.
+template <int CAP, int LO>
+__global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
+                                                   const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+                                                   const int64_t* __restrict__ tmp_off, int32_t S, int32_t* __restrict__ tmp_nbr,
+                                                   double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out, ScScratch SS,
+                                                   unsigned long long* __restrict__ live_total, const int32_t* __restrict__ worklist,
+                                                   const int32_t* __restrict__ workcount) {
+    __shared__ ScLdsT<CAP> L;
+    __shared__ WaveSortScratchT<CAP> WS;
     const WaveSortPtrs WP = {WS.ulist, WS.dlist, WS.segmark, WS.stk};
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
-    for (int32_t i = blockIdx.x; i < S; i += gridDim.x) {
+    (void)S;
+    const int32_t nwork = *workcount;
+    for (int32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const int32_t i = worklist[wi];   // lists are filled with atomics: heavy columns end up spread over the grid
         const int32_t v = (int32_t)order[i];
         const int64_t toff = tmp_off[i];
         const int32_t ex = ext[i];
@@ -1846,6 +1856,42 @@ __global__ __launch_bounds__(64) void k_sc_merge(Arrays A, const GraphDesc* __re
         if (lane == 0) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)len0); }
         __syncthreads();
     }
+}
+
+// work lists per capacity tier (0: <=64, 1: <=192, 2: the rest that k_sc_merge_big does not take, 3: k_sc_merge_big)
+__global__ __launch_bounds__(256) void k_sc_tierlists(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int tier = -1;
+    if (i < S) {
+        int32_t e = ext[i];
+        tier = e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= BIGCAP && !keyed) ? 3 : 2));
+    }
+    // one atomic per wave and tier: neighbouring columns stay neighbours in the list (locality of the
+    // staged rows), while the waves' chunks interleave (balance)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        uint64_t mk = __ballot(tier == t);
+        if (mk == 0ull) continue;
+        int32_t base = 0;
+        const int leader = __builtin_ctzll(mk);
+        if (lane == leader) base = atomicAdd(&counts[t], __popcll(mk));
+        base = __shfl(base, leader);
+        if (tier == t) lists[(size_t)t * S + base + __popcll(mk & lanemask_lt(lane))] = i;
+    }
+}
+
+void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
+                     const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
+                     unsigned long long* live_total, int32_t* lists, int32_t* counts) {
+    const int keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) ? 1 : 0;
+    hipLaunchKernelGGL(k_sc_tierlists, dim3((S + 255) / 256), dim3(256), 0, stream, ext, S, keyed, lists, counts);
+    unsigned g0 = (unsigned)(S < 256 * 32 * 4 ? S : 256 * 32 * 4);
+    unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
+    unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
+    hipLaunchKernelGGL((k_sc_merge_t<64, -1>), dim3(g0), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists, counts);
+    hipLaunchKernelGGL((k_sc_merge_t<192, 64>), dim3(g1), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + (size_t)S, counts + 1);
+    hipLaunchKernelGGL((k_sc_merge_t<SCAP, 192>), dim3(g2), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + 2 * (size_t)S, counts + 2);
 }
 
 // Long columns (SCAP < extent <= BIGCAP): one single-wave workgroup per column with the whole
