@@ -230,6 +230,164 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const int32_
 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
+// ---------------------------------------------------------------------------
+// Wave-parallel restatement of libstdc++'s std::sort (same permutation under ties as
+// rlap_core.h::gs_std_sort, which is the sequential restatement).  One wave, data in LDS.
+//   * introsort loop: the unguarded Hoare partition is done by the whole wave.  The up-scan stops at
+//     the positions with !(x < pivot), the down-scan at those with !(pivot < x); the t-th up-stop is
+//     swapped with the t-th down-stop while it lies to its left, and swapped elements are never
+//     looked at again, so both stop lists can be taken from the array as it is before the swaps.
+//     With k swaps, the cut is min(u_k, d_{k-1}).
+//   * final insertion sort == independent stable sorts of the <=16-element segments the loop leaves
+//     (everything left of a cut is <= everything right of it), one lane per segment.
+// Scratch per wave: two uint16 lists of n entries, n bits of segment marks, a small segment stack.
+// ---------------------------------------------------------------------------
+template <int CAP>
+struct WaveSortScratchT {
+    uint16_t ulist[CAP + 2];
+    uint16_t dlist[CAP + 2];
+    uint32_t segmark[(CAP + 31) / 32 + 1];
+    int32_t stk[3 * 48];
+};
+typedef WaveSortScratchT<SCAP> WaveSortScratch;
+
+struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; };
+
+template <class T, class Less>
+__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane) {
+    struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
+    if (n < 2) return;
+    const uint64_t lt = lanemask_lt(lane);
+    for (int q = lane; q < (n + 31) / 32 + 1; q += 64) W.segmark[q] = 0u;
+    WAVE_SYNC();
+    if (n <= 16) {
+        if (lane == 0) gs_insertion_sort<T>(a, n, less);
+        WAVE_SYNC();
+        return;
+    }
+    int depth0 = 0;
+    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+    depth0 *= 2;
+    int sp = 0;
+    if (lane == 0) { W.stk[0] = 0; W.stk[1] = n; W.stk[2] = depth0; }
+    sp = 1;
+    WAVE_SYNC();
+    while (sp > 0) {
+        --sp;
+        int first = W.stk[3 * sp], last = W.stk[3 * sp + 1], depth = W.stk[3 * sp + 2];
+        bool heap_sorted = false;
+        while (last - first > 16) {
+            if (depth == 0) {
+                if (lane == 0) gs_heap_sort<T>(a, first, last, less);
+                WAVE_SYNC();
+                heap_sorted = true;
+                break;
+            }
+            --depth;
+            // __move_median_to_first(first, first+1, mid, last-1), by one lane
+            if (lane == 0) {
+                int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                int pick;
+                if (less(a[ia], a[ib])) {
+                    if (less(a[ib], a[ic])) pick = ib;
+                    else if (less(a[ia], a[ic])) pick = ic;
+                    else pick = ia;
+                } else if (less(a[ia], a[ic])) pick = ia;
+                else if (less(a[ib], a[ic])) pick = ic;
+                else pick = ib;
+                T t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            WAVE_SYNC();
+            const T pv = a[first];
+            // stop lists of the two scans over [first+1, last)
+            int nu = 0, nd = 0;
+            for (int p0 = first + 1; p0 < last; p0 += 64) {
+                int p = p0 + lane;
+                bool stop = (p < last) && !less(a[p], pv);
+                uint64_t mk = __ballot(stop);
+                if (stop) W.ulist[nu + popc64(mk & lt)] = (uint16_t)p;
+                nu += popc64(mk);
+            }
+            for (int p0 = last - 1; p0 > first; p0 -= 64) {
+                int p = p0 - lane;
+                bool stop = (p > first) && !less(pv, a[p]);
+                uint64_t mk = __ballot(stop);
+                if (stop) W.dlist[nd + popc64(mk & lt)] = (uint16_t)p;
+                nd += popc64(mk);
+            }
+            if (lane == 0) W.dlist[nd] = (uint16_t)first;   // the pivot itself stops the down-scan
+            WAVE_SYNC();
+            // number of swaps: pairs (u_t, d_t) with u_t < d_t form a prefix
+            int k = 0;
+            {
+                const int tmax = nu < nd ? nu : nd;
+                bool open = true;
+                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
+                    int t = t0 + lane;
+                    bool ok = (t < tmax) && (W.ulist[t] < W.dlist[t]);
+                    uint64_t mk = __ballot(ok);
+                    // ok is monotone (true...true,false...): count the leading run
+                    uint64_t inv = ~mk;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    k += run;
+                    open = (run == 64);
+                }
+            }
+            T xu, xd;
+            for (int t0 = 0; t0 < k; t0 += 64) {
+                int t = t0 + lane;
+                if (t < k) { xu = a[W.ulist[t]]; xd = a[W.dlist[t]]; }
+                WAVE_SYNC();
+                if (t < k) { a[W.ulist[t]] = xd; a[W.dlist[t]] = xu; }
+                WAVE_SYNC();
+            }
+            int cut;
+            {
+                int cu = (k < nu) ? (int)W.ulist[k] : 0x7FFFFFFF;
+                int cd = (k > 0) ? (int)W.dlist[k - 1] : 0x7FFFFFFF;
+                cut = cu < cd ? cu : cd;
+            }
+            WAVE_SYNC();
+            // recurse on [cut,last), continue with [first,cut)
+            if (last - cut > 16) {
+                if (lane == 0) { W.stk[3 * sp] = cut; W.stk[3 * sp + 1] = last; W.stk[3 * sp + 2] = depth; }
+                ++sp;
+            } else if (lane == 0) {
+                atomicOr(&W.segmark[cut >> 5], 1u << (cut & 31));
+            }
+            WAVE_SYNC();
+            last = cut;
+        }
+        if (lane == 0) atomicOr(&W.segmark[first >> 5], 1u << (first & 31));
+        (void)heap_sorted;
+        WAVE_SYNC();
+    }
+    // final insertion sort: lane l takes the segments that start in the 32-position words l, l+64, ...
+    for (int w0 = lane; w0 * 32 < n; w0 += 64) {
+        uint32_t bits = W.segmark[w0];
+        while (bits) {
+            const int s0 = w0 * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            int e0 = n;   // end = next mark after s0, or n
+            if (bits) e0 = w0 * 32 + __builtin_ctz(bits);
+            else {
+                for (int w1 = w0 + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } }
+            }
+            for (int i = s0 + 1; i < e0; ++i) {
+                T v = a[i];
+                int j = i - 1;
+                while (j >= s0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
+                a[j + 1] = v;
+            }
+        }
+    }
+    WAVE_SYNC();
+}
+
+struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key < y.key; } };
+struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
+
+
 struct ElimLds {
     SRec rec[ECAP];  // sort records; after ordering re-used as cum[ECAP] + newv[ECAP]
     double a_val[ECAP];
@@ -237,6 +395,7 @@ struct ElimLds {
     int32_t a_slot[ECAP], a_nbr[ECAP], a_twin[ECAP];
     int32_t b_slot[ECAP], b_nbr[ECAP], b_twin[ECAP], b_pos[ECAP], b_dup[ECAP];
     int32_t ksel[ECAP], t_key[ECAP], t_mv[ECAP], t_of[ECAP], t_cnt[ECAP], t_chunk[ECAP], t_list[ECAP], t_rank[ECAP], pslot[ECAP];
+    WaveSortScratchT<ECAP> ws;
 };
 
 // Rank sort == any stable sort. Exact w.r.t. std::sort when cnt <= 16 (pure
@@ -332,10 +491,10 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
         bool done = wave_rank_sort<false>(L, len0, [&](int i) { return (double)L.a_nbr[i]; }, lane);
         WAVE_SYNC();
         if (!done) {
-            if (lane == 0) {
-                for (int i = 0; i < len0; ++i) { L.rec[i].key = (double)L.a_nbr[i]; L.rec[i].idx = i; }
-                std_sort_emul<false>(L.rec, len0);
-            }
+            const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
+            for (int i = lane; i < len0; i += 64) { L.rec[i].key = (double)L.a_nbr[i]; L.rec[i].idx = i; }
+            WAVE_SYNC();
+            wave_std_sort<SRec>(L.rec, len0, SRecLessKey(), WP, lane);
             WAVE_SYNC();
         }
     }
@@ -394,36 +553,34 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 
     // ---- order neighbours by o_n (:295-307) ----
     {
+        const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
         bool done;
         if (A.o_n == ON_RANDOM || coarsen) {
             uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
             done = wave_rank_sort<false>(L, m, [&](int i) { return keyed_order_dkey(kb, L.b_nbr[i]); }, lane);
             WAVE_SYNC();
             if (!done) {
-                if (lane == 0) {
-                    for (int i = 0; i < m; ++i) { L.rec[i].key = keyed_order_dkey(kb, L.b_nbr[i]); L.rec[i].idx = i; }
-                    std_sort_emul<false>(L.rec, m);
-                }
+                for (int i = lane; i < m; i += 64) { L.rec[i].key = keyed_order_dkey(kb, L.b_nbr[i]); L.rec[i].idx = i; }
+                WAVE_SYNC();
+                wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
                 WAVE_SYNC();
             }
         } else if (A.o_n == ON_ASC) {
             done = wave_rank_sort<false>(L, m, [&](int i) { return L.b_val[i]; }, lane);
             WAVE_SYNC();
             if (!done) {
-                if (lane == 0) {
-                    for (int i = 0; i < m; ++i) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
-                    std_sort_emul<false>(L.rec, m);
-                }
+                for (int i = lane; i < m; i += 64) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
+                WAVE_SYNC();
+                wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
                 WAVE_SYNC();
             }
         } else {
             done = wave_rank_sort<true>(L, m, [&](int i) { return L.b_val[i]; }, lane);
             WAVE_SYNC();
             if (!done) {
-                if (lane == 0) {
-                    for (int i = 0; i < m; ++i) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
-                    std_sort_emul<true>(L.rec, m);
-                }
+                for (int i = lane; i < m; i += 64) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
+                WAVE_SYNC();
+                wave_std_sort<SRec>(L.rec, m, SRecGreaterKey(), WP, lane);
                 WAVE_SYNC();
             }
         }
@@ -793,7 +950,8 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             batch_pos[v] = tid;
         }
         __syncthreads();
-        {
+        const bool first_is_big = (L.cand[0].flags & CF_BIG) != 0;   // goes to the single-vertex path: skip this round's prepare
+        if (!first_is_big) {
             // BATCH*BCAP = 4*NT slots: issue every load before the first LDS store
             static_assert(BATCH * BCAP == PASSES * NT && BCAP == BCAP_, "slot loops are unrolled for PASSES passes");
             double lv[PASSES]; int32_t ln[PASSES], lt[PASSES]; bool la[PASSES];
@@ -1009,7 +1167,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             }
         }
         __syncthreads();
-        const int32_t Pmax = s_pmax < nc ? s_pmax : nc;
+        const int32_t Pmax = first_is_big ? 0 : (s_pmax < nc ? s_pmax : nc);
         int32_t P = 0;
         PHASE_STAMP(2);
         if (Pmax > 0) {
@@ -1498,163 +1656,6 @@ __global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __re
     int32_t v = (int32_t)order[i];
     ext[i] = (colptr[v + 1] - colptr[v]) + app_cnt[v];
 }
-
-// ---------------------------------------------------------------------------
-// Wave-parallel restatement of libstdc++'s std::sort (same permutation under ties as
-// rlap_core.h::gs_std_sort, which is the sequential restatement).  One wave, data in LDS.
-//   * introsort loop: the unguarded Hoare partition is done by the whole wave.  The up-scan stops at
-//     the positions with !(x < pivot), the down-scan at those with !(pivot < x); the t-th up-stop is
-//     swapped with the t-th down-stop while it lies to its left, and swapped elements are never
-//     looked at again, so both stop lists can be taken from the array as it is before the swaps.
-//     With k swaps, the cut is min(u_k, d_{k-1}).
-//   * final insertion sort == independent stable sorts of the <=16-element segments the loop leaves
-//     (everything left of a cut is <= everything right of it), one lane per segment.
-// Scratch per wave: two uint16 lists of n entries, n bits of segment marks, a small segment stack.
-// ---------------------------------------------------------------------------
-template <int CAP>
-struct WaveSortScratchT {
-    uint16_t ulist[CAP + 2];
-    uint16_t dlist[CAP + 2];
-    uint32_t segmark[(CAP + 31) / 32 + 1];
-    int32_t stk[3 * 48];
-};
-typedef WaveSortScratchT<SCAP> WaveSortScratch;
-
-struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; };
-
-template <class T, class Less>
-__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane) {
-    struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
-    if (n < 2) return;
-    const uint64_t lt = lanemask_lt(lane);
-    for (int q = lane; q < (n + 31) / 32 + 1; q += 64) W.segmark[q] = 0u;
-    WAVE_SYNC();
-    if (n <= 16) {
-        if (lane == 0) gs_insertion_sort<T>(a, n, less);
-        WAVE_SYNC();
-        return;
-    }
-    int depth0 = 0;
-    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
-    depth0 *= 2;
-    int sp = 0;
-    if (lane == 0) { W.stk[0] = 0; W.stk[1] = n; W.stk[2] = depth0; }
-    sp = 1;
-    WAVE_SYNC();
-    while (sp > 0) {
-        --sp;
-        int first = W.stk[3 * sp], last = W.stk[3 * sp + 1], depth = W.stk[3 * sp + 2];
-        bool heap_sorted = false;
-        while (last - first > 16) {
-            if (depth == 0) {
-                if (lane == 0) gs_heap_sort<T>(a, first, last, less);
-                WAVE_SYNC();
-                heap_sorted = true;
-                break;
-            }
-            --depth;
-            // __move_median_to_first(first, first+1, mid, last-1), by one lane
-            if (lane == 0) {
-                int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
-                int pick;
-                if (less(a[ia], a[ib])) {
-                    if (less(a[ib], a[ic])) pick = ib;
-                    else if (less(a[ia], a[ic])) pick = ic;
-                    else pick = ia;
-                } else if (less(a[ia], a[ic])) pick = ia;
-                else if (less(a[ib], a[ic])) pick = ic;
-                else pick = ib;
-                T t = a[first]; a[first] = a[pick]; a[pick] = t;
-            }
-            WAVE_SYNC();
-            const T pv = a[first];
-            // stop lists of the two scans over [first+1, last)
-            int nu = 0, nd = 0;
-            for (int p0 = first + 1; p0 < last; p0 += 64) {
-                int p = p0 + lane;
-                bool stop = (p < last) && !less(a[p], pv);
-                uint64_t mk = __ballot(stop);
-                if (stop) W.ulist[nu + popc64(mk & lt)] = (uint16_t)p;
-                nu += popc64(mk);
-            }
-            for (int p0 = last - 1; p0 > first; p0 -= 64) {
-                int p = p0 - lane;
-                bool stop = (p > first) && !less(pv, a[p]);
-                uint64_t mk = __ballot(stop);
-                if (stop) W.dlist[nd + popc64(mk & lt)] = (uint16_t)p;
-                nd += popc64(mk);
-            }
-            if (lane == 0) W.dlist[nd] = (uint16_t)first;   // the pivot itself stops the down-scan
-            WAVE_SYNC();
-            // number of swaps: pairs (u_t, d_t) with u_t < d_t form a prefix
-            int k = 0;
-            {
-                const int tmax = nu < nd ? nu : nd;
-                bool open = true;
-                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
-                    int t = t0 + lane;
-                    bool ok = (t < tmax) && (W.ulist[t] < W.dlist[t]);
-                    uint64_t mk = __ballot(ok);
-                    // ok is monotone (true...true,false...): count the leading run
-                    uint64_t inv = ~mk;
-                    int run = inv ? __builtin_ctzll(inv) : 64;
-                    k += run;
-                    open = (run == 64);
-                }
-            }
-            T xu, xd;
-            for (int t0 = 0; t0 < k; t0 += 64) {
-                int t = t0 + lane;
-                if (t < k) { xu = a[W.ulist[t]]; xd = a[W.dlist[t]]; }
-                WAVE_SYNC();
-                if (t < k) { a[W.ulist[t]] = xd; a[W.dlist[t]] = xu; }
-                WAVE_SYNC();
-            }
-            int cut;
-            {
-                int cu = (k < nu) ? (int)W.ulist[k] : 0x7FFFFFFF;
-                int cd = (k > 0) ? (int)W.dlist[k - 1] : 0x7FFFFFFF;
-                cut = cu < cd ? cu : cd;
-            }
-            WAVE_SYNC();
-            // recurse on [cut,last), continue with [first,cut)
-            if (last - cut > 16) {
-                if (lane == 0) { W.stk[3 * sp] = cut; W.stk[3 * sp + 1] = last; W.stk[3 * sp + 2] = depth; }
-                ++sp;
-            } else if (lane == 0) {
-                atomicOr(&W.segmark[cut >> 5], 1u << (cut & 31));
-            }
-            WAVE_SYNC();
-            last = cut;
-        }
-        if (lane == 0) atomicOr(&W.segmark[first >> 5], 1u << (first & 31));
-        (void)heap_sorted;
-        WAVE_SYNC();
-    }
-    // final insertion sort: lane l takes the segments that start in the 32-position words l, l+64, ...
-    for (int w0 = lane; w0 * 32 < n; w0 += 64) {
-        uint32_t bits = W.segmark[w0];
-        while (bits) {
-            const int s0 = w0 * 32 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            int e0 = n;   // end = next mark after s0, or n
-            if (bits) e0 = w0 * 32 + __builtin_ctz(bits);
-            else {
-                for (int w1 = w0 + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } }
-            }
-            for (int i = s0 + 1; i < e0; ++i) {
-                T v = a[i];
-                int j = i - 1;
-                while (j >= s0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
-                a[j + 1] = v;
-            }
-        }
-    }
-    WAVE_SYNC();
-}
-
-struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key < y.key; } };
-struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
 
 // test hook: one wave sorts one array of doubles, returns the permutation (tests/test_gpu_parity.py)
 __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict__ keys, const int32_t* __restrict__ offs, int32_t narr,
