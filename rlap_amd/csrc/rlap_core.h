@@ -637,9 +637,14 @@ struct Ent {
 enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8, CF_TIE = 16, CF_NEQ = 32, CF_READY = 64 };
 enum { TF_CONTENDED = 1 };
 
-struct Cand {
-    Ent e[BCAP];
-    uint8_t ksel[BCAP];
+// BC = live entries a candidate may hold (32: one half-wave per candidate, 64: one wave).
+template <int BC> struct CandPad {};
+template <> struct CandPad<64> { int64_t pad64; };   // keeps the LDS stride of CandT<64> off the 64-bank period
+template <int BC>
+struct CandT : CandPad<BC> {
+    static constexpr int CAP = BC;
+    Ent e[BC];
+    uint8_t ksel[BC];
     int32_t v;
     int32_t m;        // live (= distinct) neighbours
     int32_t flags;
@@ -649,9 +654,10 @@ struct Cand {
     int32_t cp1;      // colptr[v+1]
     int32_t acnt;     // appended entries
     int32_t ext;      // slots to read (appended + CSR), dead ones included
-    int32_t cb[3];    // bases of the appended chunks 0..2
+    int32_t cb[BC <= 32 ? 3 : 4];   // bases of the appended chunks
     int64_t draw0;    // first uniform
-};   // 856 B: an even, non-power-of-two word stride keeps per-candidate LDS accesses ~conflict free
+};   // 856 B (BC=32) / 1672 B (BC=64): word strides 214 / 418 share only a factor 2 with the 64 LDS banks
+typedef CandT<BCAP> Cand;
 
 RLAP_HD TRes& ent_tres(Ent& e) { return e.res; }
 
@@ -679,31 +685,39 @@ struct KIGreater { RLAP_HD bool operator()(const KI& x, const KI& y) const { ret
 
 // o_n order of a candidate whose entries are already sorted by id and carry the sort key
 // in aux (weight, or the keyed-order key): leaves the source index of position j in ksel[j].
-RLAP_HD void cand_order_index(const Arrays& A, Cand& C) {
+template <class CT>
+RLAP_HD void cand_order_index(const Arrays& A, CT& C) {
     const int32_t m = C.m;
     for (int32_t j = 0; j < m; ++j) C.ksel[j] = (uint8_t)j;
     KIArr arr; arr.e = C.e; arr.ix = C.ksel;
-    if (A.o_n == ON_DESC && A.o_v != OV_COARSEN) gs_std_sort_small<KI>(arr, m, KIGreater());
-    else gs_std_sort_small<KI>(arr, m, KILess());
+    if (CT::CAP <= 32) {   // the stack-free variant is only valid up to 32 elements
+        if (A.o_n == ON_DESC && A.o_v != OV_COARSEN) gs_std_sort_small<KI>(arr, m, KIGreater());
+        else gs_std_sort_small<KI>(arr, m, KILess());
+    } else {
+        if (A.o_n == ON_DESC && A.o_v != OV_COARSEN) gs_std_sort<KI>(arr, m, KIGreater());
+        else gs_std_sort<KI>(arr, m, KILess());
+    }
     C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
 }
 
 // Candidate preparation in three steps so the loads can be spread over all
 // threads: cand_meta (one per candidate), cand_load (one per slot), cand_finish.
-RLAP_HD void cand_meta(const Arrays& A, int32_t v, Cand& C) {
+template <class CT>
+RLAP_HD void cand_meta(const Arrays& A, int32_t v, CT& C) {
     C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0;
     int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
     int32_t acnt = A.app_cnt[v];
     C.cp1 = cp1; C.acnt = acnt; C.ext = (cp1 - cp0) + acnt;
-    if (C.ext > BCAP) { C.flags = CF_BIG; C.ext = 0; return; }
+    if (C.ext > CT::CAP) { C.flags = CF_BIG; C.ext = 0; return; }
     if (acnt > 0) {
-        int ct = chunk_of(acnt - 1);            // <= 2 because acnt <= BCAP
+        int ct = chunk_of(acnt - 1);            // <= 2 (CAP 32) / <= 3 (CAP 64) because acnt <= CAP
         int32_t base = A.app_chunk[v];
         for (int c = ct; c >= 0; --c) { C.cb[c] = base; if (c > 0) base = A.e_nbr[base]; }
     }
 }
 // traversal position e of the column (:248-271): appended entries newest first, then the CSR segment backwards
-RLAP_HD int32_t cand_slot(const Cand& C, int32_t e) {
+template <class CT>
+RLAP_HD int32_t cand_slot(const CT& C, int32_t e) {
     if (e < C.acnt) {
         int32_t a = C.acnt - 1 - e;
         int c = chunk_of(a);
@@ -711,12 +725,14 @@ RLAP_HD int32_t cand_slot(const Cand& C, int32_t e) {
     }
     return C.cp1 - 1 - (e - C.acnt);
 }
-RLAP_HD void cand_load(const Arrays& A, Cand& C, int32_t e) {
+template <class CT>
+RLAP_HD void cand_load(const Arrays& A, CT& C, int32_t e) {
     int32_t s = cand_slot(C, e);
     C.e[e].val = A.e_val[s]; C.e[e].nbr = A.e_nbr[s]; C.e[e].twin = A.e_twin[s]; C.e[e].aux = 0;
 }
 // drop dead entries -> sort by id (:275) -> multi-edges go to the single-vertex path -> order by o_n (:295-307)
-RLAP_HD void cand_finish(const Arrays& A, Cand& C) {
+template <class CT>
+RLAP_HD void cand_finish(const Arrays& A, CT& C) {
     if (C.flags & CF_BIG) return;
     int32_t len = 0;
     for (int32_t e = 0; e < C.ext; ++e) {
@@ -736,7 +752,8 @@ RLAP_HD void cand_finish(const Arrays& A, Cand& C) {
     }
     C.ndraw = (A.o_v == OV_COARSEN) ? (len >= 1 ? 1 : 0) : (len > 1 ? len - 1 : 0);
 }
-RLAP_HD void cand_prepare(const Arrays& A, int32_t v, Cand& C) {
+template <class CT>
+RLAP_HD void cand_prepare(const Arrays& A, int32_t v, CT& C) {
     cand_meta(A, v, C);
     for (int32_t e = 0; e < C.ext; ++e) cand_load(A, C, e);
     cand_finish(A, C);
@@ -753,7 +770,8 @@ RLAP_HD int32_t ent_upper_index(const Ent* e, int32_t m, double r) {  // first a
 
 // cumulative weights (:366-373); coarsen also draws its single target and the
 // collapsed weights here (:867-897)
-RLAP_HD void cand_cumsum(const Arrays& A, Cand& C) {
+template <class CT>
+RLAP_HD void cand_cumsum(const Arrays& A, CT& C) {
     const int32_t m = C.m;
     double csum = 0;
     for (int32_t j = 0; j < m; ++j) { csum += C.e[j].val; C.e[j].aux = csum; }
@@ -772,7 +790,8 @@ RLAP_HD void cand_cumsum(const Arrays& A, Cand& C) {
     }
 }
 // sampled target of position j < m-1 (:385-394); degree/random only
-RLAP_HD void cand_pick(const Arrays& A, Cand& C, int32_t j) {
+template <class CT>
+RLAP_HD void cand_pick(const Arrays& A, CT& C, int32_t j) {
     const int32_t m = C.m;
     double csum = C.e[m - 1].aux;
     double u = A.rng[C.draw0 + j];
@@ -781,7 +800,8 @@ RLAP_HD void cand_pick(const Arrays& A, Cand& C, int32_t j) {
     C.ksel[j] = (uint8_t)ent_upper_index(C.e, m, r);
 }
 // the f / colScale / wdeg recurrences (:374-417): leaves the new edge weight of position j in e[j].val
-RLAP_HD void cand_recur(const Arrays& A, Cand& C) {
+template <class CT>
+RLAP_HD void cand_recur(const Arrays& A, CT& C) {
     if (A.o_v == OV_COARSEN) return;
     const int32_t m = C.m;
     if (m < 1) return;
@@ -795,7 +815,8 @@ RLAP_HD void cand_recur(const Arrays& A, Cand& C) {
         wdeg = wdeg * omf * omf;
     }
 }
-RLAP_HD void cand_sample(const Arrays& A, Cand& C) {
+template <class CT>
+RLAP_HD void cand_sample(const Arrays& A, CT& C) {
     cand_cumsum(A, C);
     if (A.o_v != OV_COARSEN) for (int32_t j = 0; j < C.m - 1; ++j) cand_pick(A, C, j);
     cand_recur(A, C);
@@ -805,7 +826,8 @@ RLAP_HD void cand_sample(const Arrays& A, Cand& C) {
 // (valid while every intermediate key stays <= n, where each change moves the
 // vertex; otherwise *complex is set).  Returns the new key; *mv = op number of
 // the last move or -1; *cnt = pushes into the target's column.
-RLAP_HD int32_t cand_replay(const Arrays& A, const Cand& C, int32_t j, int32_t key0, int32_t n, bool allow_last_dec,
+template <class CT>
+RLAP_HD int32_t cand_replay(const Arrays& A, const CT& C, int32_t j, int32_t key0, int32_t n, bool allow_last_dec,
                             int* mv, int* cnt, bool* complex) {
     const int32_t m = C.m;
     int32_t key = key0;

@@ -736,27 +736,28 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 // ---------------------------------------------------------------------------
 constexpr int NT = 1024;      // threads per workgroup of the batch kernel (measured faster than 512 despite tighter registers)
 constexpr int NWAVE = NT / 64;
-constexpr int BATCH = 128;    // candidates per round
-constexpr int BCAP_ = 32;
-constexpr int PASSES = BATCH * BCAP_ / NT;   // (candidate, slot) pairs per thread
+constexpr int SLOTS = 4096;   // candidates x slots per round: 128 x 32 (one half-wave per candidate) or 64 x 64 (one wave)
+constexpr int PASSES = SLOTS / NT;   // (candidate, slot) pairs per thread
 constexpr int MCAP = NT;      // PQ moves per round: one per thread, sorted in registers + LDS
 constexpr int CCAP = 512;     // contended (target, candidate) records per round
 
 struct CRec { int32_t x, i, j; };
 
-struct BatchLds {
-    Cand cand[BATCH];
+template <int BC>
+struct BatchLdsT {
+    CandT<BC> cand[SLOTS / BC];
     uint64_t mkey[MCAP];
     int32_t mval[MCAP];
     int32_t hidx[MCAP];
-    int32_t pslot[BATCH * BCAP_];   // slot of the entry position p of candidate i appends (commit phase)
+    int32_t pslot[SLOTS];   // slot of the entry position p of candidate i appends (commit phase)
     CRec cont[CCAP];
     CRec csorted[CCAP];
     int32_t scan[NWAVE + 8];
 };
 
-union ElimShared {
-    BatchLds b;
+template <int BC>
+union ElimSharedT {
+    BatchLdsT<BC> b;
     ElimLds e;
 };
 
@@ -788,7 +789,8 @@ __device__ __forceinline__ void rewire_store(const Arrays& A, int32_t s_r, int32
 }
 
 // all pushes of candidate C into the column of its target at position j, in position order
-__device__ __forceinline__ void push_into_target(const Arrays& A, const Cand& C, int32_t j, int32_t& a, int32_t& chunk, int32_t* status) {
+template <class CT>
+__device__ __forceinline__ void push_into_target(const Arrays& A, const CT& C, int32_t j, int32_t& a, int32_t& chunk, int32_t* status) {
     const int32_t x = C.e[j].nbr;
     if (A.o_v == OV_COARSEN) {
         if (j != C.koff) return;
@@ -809,7 +811,8 @@ __device__ __forceinline__ void push_into_target(const Arrays& A, const Cand& C,
 }
 
 // slots for all pushes of candidate C into the column of its target at position j (position order)
-__device__ __forceinline__ void slots_into_target(const Arrays& A, const Cand& C, int32_t j, int32_t& a, int32_t& chunk, int32_t* status, int32_t* pslot_row) {
+template <class CT>
+__device__ __forceinline__ void slots_into_target(const Arrays& A, const CT& C, int32_t j, int32_t& a, int32_t& chunk, int32_t* status, int32_t* pslot_row) {
     const bool co = A.o_v == OV_COARSEN;
     if (co && j != C.koff) return;
     const int32_t plast = co ? C.m : C.m - 1;
@@ -820,7 +823,8 @@ __device__ __forceinline__ void slots_into_target(const Arrays& A, const Cand& C
     }
 }
 
-__device__ __noinline__ void cand_order_index_call(const Arrays& A, Cand& C) { cand_order_index(A, C); }
+template <class CT>
+__device__ __noinline__ void cand_order_index_call(const Arrays& A, CT& C) { cand_order_index(A, C); }
 
 __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G, const ElimScratch& S, int32_t v0, int64_t e1) {
     ColBuf Bf = S.colbuf(G.scr_base);
@@ -830,29 +834,37 @@ __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G
 
 // Specialised on (o_v, o_n): the mode tests fold away, which keeps the round loop's code (executed once
 // per round by every wave) small enough for the instruction cache.
-template <int OV, int ON>
+template <int OV, int ON, int BC>
 __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
                                                            int32_t* __restrict__ batch_pos, int32_t* __restrict__ tcount) {
+    // BC slots per candidate: a group of BC lanes (half a wave or a whole wave) works on one candidate
+    constexpr int BCAP = BC;
+    constexpr int BATCH = SLOTS / BC;
+    typedef CandT<BC> Cand;
+    typedef BatchLdsT<BC> BatchLds;
+    constexpr int GSH = 64 - BC;                                  // lane & GSH = first lane of my group
+    constexpr uint64_t GMASK = BC == 64 ? ~0ull : 0xFFFFFFFFull;   // a group's part of a 64-bit ballot
     Arrays A = A_in;
     A.o_v = OV;
     A.o_n = ON;
-    __shared__ ElimShared sh;
+    __shared__ ElimSharedT<BC> sh;
     __shared__ GraphDesc G;
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status;
-    __shared__ uint8_t s_eqperm[16][32];   // std::sort's permutation of n = 17..32 all-equal keys
-    __shared__ uint8_t s_eqinv[16][32];    // its inverse: final position of the entry with id-rank r
+    __shared__ uint8_t s_eqperm[BC - 16][BC];   // std::sort's permutation of n = 17..BC all-equal keys
+    __shared__ uint8_t s_eqinv[BC - 16][BC];    // its inverse: final position of the entry with id-rank r
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid == 0) { G = gd[g]; s_status = 0; }
-    if (tid < 16) {
+    if (tid < BC - 16) {
         Cand& C = L.cand[tid];
         const int nn = 17 + tid;
         for (int q = 0; q < nn; ++q) { C.e[q].aux = 1.0; C.ksel[q] = (uint8_t)q; }
-        KIArr arr; arr.e = C.e; arr.ix = C.ksel;
-        gs_std_sort_small<KI>(arr, nn, KILess());
-        for (int q = 0; q < 32; ++q) s_eqperm[tid][q] = q < nn ? C.ksel[q] : (uint8_t)q;
-        for (int q = 0; q < 32; ++q) s_eqinv[tid][s_eqperm[tid][q]] = (uint8_t)q;
+        C.m = nn;
+        Arrays A3 = A;
+        cand_order_index_call(A3, C);   // all keys equal: asc and desc compare alike
+        for (int q = 0; q < BC; ++q) s_eqperm[tid][q] = q < nn ? C.ksel[q] : (uint8_t)q;
+        for (int q = 0; q < BC; ++q) s_eqinv[tid][s_eqperm[tid][q]] = (uint8_t)q;
     }
     __syncthreads();
     const int32_t n = G.n;
@@ -953,7 +965,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
         const bool first_is_big = (L.cand[0].flags & CF_BIG) != 0;   // goes to the single-vertex path: skip this round's prepare
         if (!first_is_big) {
             // BATCH*BCAP = 4*NT slots: issue every load before the first LDS store
-            static_assert(BATCH * BCAP == PASSES * NT && BCAP == BCAP_, "slot loops are unrolled for PASSES passes");
+            static_assert(BATCH * BCAP == PASSES * NT && (BC == 32 || BC == 64), "slot loops are unrolled for PASSES passes");
             double lv[PASSES]; int32_t ln[PASSES], lt[PASSES]; bool la[PASSES];
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
@@ -976,23 +988,23 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, e = idx % BCAP;
-                const int hb = lane & 32;
+                const int hb = lane & GSH;
                 const bool live = la[k] && lv[k] > 0;
-                const uint32_t half = (uint32_t)(__ballot(live) >> hb);
+                const uint64_t half = (__ballot(live) >> hb) & GMASK;
                 const int32_t nxt = __shfl_down(ln[k], 1);
                 const bool cand_ok = (i < nc) && !(L.cand[i].flags & CF_BIG);
                 const int32_t ext = cand_ok ? L.cand[i].ext : 0;
                 const bool unsorted = la[k] && (e + 1 < ext) && !(ln[k] > nxt);
-                const uint32_t hbad = (uint32_t)(__ballot(unsorted) >> hb);
-                const int f = half ? __builtin_ctz(half) : 0;
+                const uint64_t hbad = (__ballot(unsorted) >> hb) & GMASK;
+                const int f = half ? __builtin_ctzll(half) : 0;
                 const double w0 = __shfl(lv[k], hb + f);
-                const uint32_t hdw = (uint32_t)(__ballot(live && lv[k] != w0) >> hb);
+                const uint64_t hdw = (__ballot(live && lv[k] != w0) >> hb) & GMASK;
                 ready[k] = cand_ok && !keyed && L.cand[i].acnt == 0 && hbad == 0 && hdw == 0;
                 if (ready[k]) {
                     Cand& C = L.cand[i];
-                    const int32_t m = __popc(half);
+                    const int32_t m = __popcll(half);
                     if (live) {
-                        const int32_t r = __popc(half & ~((2u << e) - 1u));
+                        const int32_t r = __popcll(half & ~((2ull << e) - 1ull));
                         const int32_t pos = (m <= 16) ? r : (int32_t)s_eqinv[m - 17][r];
                         Ent& E = C.e[pos];
                         E.val = lv[k]; E.nbr = ln[k]; E.twin = lt[k]; E.aux = 0;
@@ -1027,18 +1039,18 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, e = idx % BCAP;
                 const bool live = la[k] && lv[k] > 0;
-                const uint32_t half = (uint32_t)(__ballot(live) >> (lane & 32));
+                const uint64_t half = (__ballot(live) >> (lane & GSH)) & GMASK;
                 // in-place twin rewrites (:404-406) can leave a CSR segment unsorted: the shortcut needs
                 // every slot (live or dead) strictly above its successor
                 const int32_t nxt = __shfl_down(ln[k], 1);
                 const bool unsorted = la[k] && (i < nc) && (e + 1 < L.cand[i].ext) && !(ln[k] > nxt);
-                const uint32_t hbad = (uint32_t)(__ballot(unsorted) >> (lane & 32));
+                const uint64_t hbad = (__ballot(unsorted) >> (lane & GSH)) & GMASK;
                 rk[k] = -1;
                 if (!ready[k] && i < nc && L.cand[i].ext > 0) {
                     Cand& C = L.cand[i];
                     if (C.acnt == 0 && hbad == 0) {
-                        if (live) rk[k] = __popc(half & ~((2u << e) - 1u));
-                        if (e == 0) C.m = __popc(half);
+                        if (live) rk[k] = __popcll(half & ~((2ull << e) - 1ull));
+                        if (e == 0) C.m = __popcll(half);
                     } else if (live) {
                         const int32_t ext = C.ext, me = ln[k];
                         int32_t r = 0, nlive = 0;
@@ -1087,7 +1099,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                 if (__ballot(valid) == 0ull) continue;
                 double kme = 0, k0 = 0;
                 if (valid) { kme = L.cand[i].e[j].aux; k0 = L.cand[i].e[0].aux; }
-                const uint32_t hdiff = (uint32_t)(__ballot(valid && kme != k0) >> (lane & 32));
+                const uint64_t hdiff = (__ballot(valid && kme != k0) >> (lane & GSH)) & GMASK;
                 if (valid) {
                     Cand& C = L.cand[i];
                     const int32_t m = C.m;
@@ -1609,10 +1621,12 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
 
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
                             int32_t* batch_pos, int32_t* tcount) {
-#define RLAP_CASE(OV, ON) if (o_v == OV && o_n == ON) { hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON>), dim3(G), dim3(NT), 0, stream, A, gd, S, batch_pos, tcount); return; }
-    RLAP_CASE(OV_RANDOM, ON_ASC) RLAP_CASE(OV_RANDOM, ON_DESC) RLAP_CASE(OV_RANDOM, ON_RANDOM)
-    RLAP_CASE(OV_DEGREE, ON_ASC) RLAP_CASE(OV_DEGREE, ON_DESC) RLAP_CASE(OV_DEGREE, ON_RANDOM)
-    RLAP_CASE(OV_COARSEN, ON_ASC) RLAP_CASE(OV_COARSEN, ON_DESC) RLAP_CASE(OV_COARSEN, ON_RANDOM)
+    // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
+    // turn comes): it runs with 64 slots per candidate (64 candidates per round); the min-degree orders with 32.
+#define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC>), dim3(G), dim3(NT), 0, stream, A, gd, S, batch_pos, tcount); return; }
+    RLAP_CASE(OV_RANDOM, ON_ASC, 64) RLAP_CASE(OV_RANDOM, ON_DESC, 64) RLAP_CASE(OV_RANDOM, ON_RANDOM, 64)
+    RLAP_CASE(OV_DEGREE, ON_ASC, 32) RLAP_CASE(OV_DEGREE, ON_DESC, 32) RLAP_CASE(OV_DEGREE, ON_RANDOM, 32)
+    RLAP_CASE(OV_COARSEN, ON_ASC, 32) RLAP_CASE(OV_COARSEN, ON_DESC, 32) RLAP_CASE(OV_COARSEN, ON_RANDOM, 32)
 #undef RLAP_CASE
 }
 
