@@ -384,6 +384,113 @@ __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int
     WAVE_SYNC();
 }
 
+// ---------------------------------------------------------------------------
+// The same restatement for n <= 64 with ONE ELEMENT PER LANE (key and source index in registers):
+// partitions exchange elements with ds_bpermute instead of LDS round trips, the two stop lists are
+// rank-indexed lane ids in a 2 x 66 int LDS scratch, the segment marks are one 64-bit mask and the
+// final insertion sort is a stable rank inside each <=16-element segment.  On return lane p holds
+// in `key`/`idx` an arbitrary element; *pos = final position of the element the lane holds, so the caller
+// stores out[*pos] = idx.  Returns false (nothing usable) if the depth limit is hit -- the caller falls
+// back to the sequential restatement (heap-sort branch).
+// ---------------------------------------------------------------------------
+template <bool DESC>
+__device__ __forceinline__ bool wave_sort64(double& key, int& idx, const int n, const int lane, int32_t* tmp, int* pos) {
+    auto less = [](double x, double y) { return DESC ? (x > y) : (x < y); };
+    int32_t* tmpu = tmp;
+    int32_t* tmpd = tmp + 66;
+    int32_t* stk = tmp + 132;   // 3 ints per pending segment, at most 3 pending
+    const uint64_t lt = lanemask_lt(lane);
+    const uint64_t gt = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+    uint64_t segmask = 0ull;
+    bool ok_depth = true;
+    if (n > 16) {
+        int depth0 = 0;
+        for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+        depth0 *= 2;
+        int sp = 0;
+        int first = 0, last = n, depth = depth0;
+        while (true) {
+            while (last - first > 16) {
+                if (depth == 0) { ok_depth = false; break; }
+                --depth;
+                // __move_median_to_first(first, first+1, mid, last-1)
+                const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                const double ka = __shfl(key, ia), kb = __shfl(key, ib), kc = __shfl(key, ic);
+                int pick;
+                if (less(ka, kb)) {
+                    if (less(kb, kc)) pick = ib;
+                    else if (less(ka, kc)) pick = ic;
+                    else pick = ia;
+                } else if (less(ka, kc)) pick = ia;
+                else if (less(kb, kc)) pick = ic;
+                else pick = ib;
+                {
+                    const double kf = __shfl(key, first), kp = __shfl(key, pick);
+                    const int xf = __shfl(idx, first), xp = __shfl(idx, pick);
+                    if (lane == first) { key = kp; idx = xp; }
+                    else if (lane == pick) { key = kf; idx = xf; }
+                }
+                const double pv = __shfl(key, first);
+                const bool inr = lane > first && lane < last;
+                const bool su = inr && !less(key, pv);
+                const bool sd = inr && !less(pv, key);
+                const uint64_t mu = __ballot(su), md = __ballot(sd);
+                const int nu = popc64(mu), nd = popc64(md);
+                const int ru = popc64(mu & lt), rd = popc64(md & gt);
+                if (su) tmpu[ru] = lane;
+                if (sd) tmpd[rd] = lane;
+                if (lane == 0) tmpd[nd] = first;   // the pivot itself stops the down-scan
+                WAVE_SYNC();
+                const int tmax = nu < nd ? nu : nd;
+                const bool okp = (lane < tmax) && (tmpu[lane] < tmpd[lane]);
+                const int k = popc64(__ballot(okp));   // a prefix of the pairs
+                int partner = lane;
+                if (su && ru < k) partner = tmpd[ru];
+                else if (sd && rd < k) partner = tmpu[rd];
+                int cu = 0x7FFFFFFF, cd = 0x7FFFFFFF;
+                if (k < nu) cu = tmpu[k];
+                if (k > 0) cd = tmpd[k - 1];
+                const int cut = cu < cd ? cu : cd;
+                WAVE_SYNC();
+                key = __shfl(key, partner);
+                idx = __shfl(idx, partner);
+                if (last - cut > 16) {
+                    if (lane == 0) { stk[3 * sp] = cut; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth; }
+                    ++sp;
+                } else {
+                    segmask |= 1ull << cut;
+                }
+                last = cut;
+            }
+            if (!ok_depth) break;
+            segmask |= 1ull << first;
+            if (sp == 0) break;
+            --sp;
+            WAVE_SYNC();
+            first = stk[3 * sp]; last = stk[3 * sp + 1]; depth = stk[3 * sp + 2];
+            WAVE_SYNC();
+        }
+    } else {
+        segmask = 1ull;
+    }
+    if (!ok_depth) return false;
+    // final insertion sort == stable sort of every marked segment: my rank inside my segment
+    const int l2 = lane < n ? lane : 0;
+    const uint64_t below = segmask & (lt | (1ull << l2));
+    const int s0 = 63 - __builtin_clzll(below | 1ull);
+    const uint64_t above = (l2 == 63) ? 0ull : (segmask >> (l2 + 1));
+    const int e0 = above ? (l2 + 1 + __builtin_ctzll(above)) : n;
+    int cnt = 0;
+    for (int q = 0; q < 16; ++q) {
+        const int p = s0 + q;
+        const double kq = __shfl(key, p < 64 ? p : 63);
+        const bool in = p < e0 && p != lane;
+        cnt += (in && (less(kq, key) || (!less(key, kq) && p < lane))) ? 1 : 0;
+    }
+    *pos = s0 + cnt;
+    return true;
+}
+
 struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key < y.key; } };
 struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
 
@@ -1132,7 +1239,32 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     if (C.m <= 16 || !(C.flags & CF_TIE)) C.ksel[r2[k]] = (uint8_t)(idx % BCAP);
                 }
             }
-            if (tid < nc) {
+            if (BC == 64) {
+                // one wave = one candidate: std::sort's permutation with the elements in registers
+                __syncthreads();   // rank writes of ksel above vs. the sort's own
+                int32_t* tmp = L.pslot + (tid >> 6) * 256;   // pslot is not live before the commit
+#pragma unroll 1
+                for (int k = 0; k < PASSES; ++k) {
+                    const int32_t i = k * NWAVE + (tid >> 6);
+                    if (i >= nc) break;
+                    Cand& C = L.cand[i];
+                    const int32_t fl = C.flags, m = C.m;
+                    if ((fl & (CF_BIG | CF_DUP | CF_READY)) || !(m > 16 && (fl & CF_TIE) && (fl & CF_NEQ))) continue;
+                    double key = lane < m ? C.e[lane].aux : 0.0;
+                    int idx = lane, pos = lane;
+                    const bool ok = desc ? wave_sort64<true>(key, idx, m, lane, tmp, &pos) : wave_sort64<false>(key, idx, m, lane, tmp, &pos);
+                    if (ok) { if (lane < m) C.ksel[pos] = (uint8_t)idx; }
+                    else if (lane == 0) { Arrays A3 = A; cand_order_index_call(A3, C); }
+                    WAVE_SYNC();
+                }
+                if (tid < nc) {
+                    Cand& C = L.cand[tid];
+                    if (!(C.flags & (CF_BIG | CF_DUP | CF_READY))) {
+                        const int32_t m = C.m;
+                        C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
+                    }
+                }
+            } else if (tid < nc) {
                 Cand& C = L.cand[tid];
                 if (!(C.flags & (CF_BIG | CF_DUP | CF_READY))) {
                     const int32_t m = C.m;
@@ -1676,13 +1808,22 @@ __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict
                                                         int32_t desc, int32_t* __restrict__ perm_out) {
     __shared__ SRec rec[SCAP];
     __shared__ WaveSortScratch W;
+    __shared__ int32_t tmp64[160];
     const int lane = lane_id();
     for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
         const int32_t o = offs[arr], n = offs[arr + 1] - o;
         for (int q = lane; q < n; q += 64) { rec[q].key = keys[o + q]; rec[q].idx = q; rec[q].aux = 0; }
         __syncthreads();
         WaveSortPtrs WP = {W.ulist, W.dlist, W.segmark, W.stk};
-        if (desc) wave_std_sort<SRec>(rec, n, SRecGreaterKey(), WP, lane); else wave_std_sort<SRec>(rec, n, SRecLessKey(), WP, lane);
+        if ((desc & 2) && n <= 64) {   // register-resident variant (batch candidates of the 64-slot kernel)
+            double key = lane < n ? rec[lane].key : 0.0;
+            int idx = lane, pos = lane;
+            bool ok = (desc & 1) ? wave_sort64<true>(key, idx, n, lane, tmp64, &pos) : wave_sort64<false>(key, idx, n, lane, tmp64, &pos);
+            if (lane < n) perm_out[o + (ok ? pos : lane)] = ok ? idx : -1;
+            __syncthreads();
+            continue;
+        }
+        if (desc & 1) wave_std_sort<SRec>(rec, n, SRecGreaterKey(), WP, lane); else wave_std_sort<SRec>(rec, n, SRecLessKey(), WP, lane);
         __syncthreads();
         for (int q = lane; q < n; q += 64) perm_out[o + q] = rec[q].idx;
         __syncthreads();

@@ -117,58 +117,13 @@ struct Setup {
 
 }  // namespace
 
-extern "C" {
-
-// std_sort_emul permutation of doubles: perm_out[i] = original index ending at i.
-void mirror_sort_perm(const double* keys, int64_t n, int desc, int64_t* perm_out) {
-    std::vector<SRec> r((size_t)n);
-    for (int64_t i = 0; i < n; ++i) { r[i].key = keys[i]; r[i].idx = (int32_t)i; r[i].aux = 0; }
-    if (desc) std_sort_emul<true>(r.data(), (int)n); else std_sort_emul<false>(r.data(), (int)n);
-    for (int64_t i = 0; i < n; ++i) perm_out[i] = r[i].idx;
-}
-
-// n <= 32: the stack-free variant used for batch candidates, on the (key,index) proxy view
-void mirror_sort_perm_small(const double* keys, int64_t n, int desc, int64_t* perm_out) {
-    Cand C;
-    for (int64_t i = 0; i < n; ++i) { C.e[i].aux = keys[i]; C.ksel[i] = (uint8_t)i; }
-    KIArr arr; arr.e = C.e; arr.ix = C.ksel;
-    if (desc) gs_std_sort_small<KI>(arr, (int)n, KIGreater()); else gs_std_sort_small<KI>(arr, (int)n, KILess());
-    for (int64_t i = 0; i < n; ++i) perm_out[i] = C.ksel[i];
-}
-
-void mirror_heapsort_perm(const double* keys, int64_t n, int desc, int64_t* perm_out) {
-    std::vector<SRec> r((size_t)n);
-    for (int64_t i = 0; i < n; ++i) { r[i].key = keys[i]; r[i].idx = (int32_t)i; r[i].aux = 0; }
-    if (desc) ss_heap_sort<true>(r.data(), 0, (int)n); else ss_heap_sort<false>(r.data(), 0, (int)n);
-    for (int64_t i = 0; i < n; ++i) perm_out[i] = r[i].idx;
-}
-
-// Coalesced, symmetric COO in (row[], col[], w[]) -> Schur complement rows,
-// sequential driver.  Single graph. Returns status; *out malloc'd (m,3).
-int mirror_approx_chol(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
-                       int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots,
-                       double** out, int64_t* out_rows, int64_t* order_out) {
-    Setup S;
-    S.build(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots);
-    int64_t nelim = std::min<int64_t>(t, n - 1);
-    if (nelim < 0) nelim = 0;
-    int64_t npop = 0;
-    for (int64_t e1 = 1; e1 <= nelim; ++e1) {
-        int32_t v = (o_v == OV_RANDOM) ? (int32_t)S.perm_l[n - e1] : pq_pop(S.A, S.G);
-        if (order_out) order_out[npop] = v;
-        ++npop;
-        int rc = serial_eliminate(S.A, S.G, S.B, S.cap, v, e1);
-        if (rc) return rc;
-    }
-    return S.finish(nelim, npop, order_out, out, out_rows);
-}
-
 // Batch driver: the round structure of the frontier kernel, executed with plain
 // loops.  Every step uses only what the parallel kernel has at that point
 // (pre-round global state + per-candidate records), so a logic error in the
 // batching rules shows up here as a mismatch with the oracle.
 // stats_out[0] = rounds, [1] = single-vertex fallbacks, [2] = contended targets.
-int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
+template <int BC>
+static int mirror_batch_impl(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
                              int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t Bsz,
                              double** out, int64_t* out_rows, int64_t* order_out, int64_t* stats_out) {
     Setup S;
@@ -179,7 +134,10 @@ int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const doubl
     int64_t nelim = std::min<int64_t>(t, n - 1);
     if (nelim < 0) nelim = 0;
     int64_t done = 0, npop = 0, rounds = 0, singles = 0, contended_total = 0;
+    typedef CandT<BC> Cand;
     std::vector<Cand> cand((size_t)Bsz);
+    int64_t why[6] = {0, 0, 0, 0, 0, 0};
+    int64_t single_len = 0, single_gt384 = 0, single_gt384_len = 0, single_max = 0;  // adjacent, big, dup, complex, pre-empted, full
     std::vector<int32_t> batch_pos((size_t)n, -1), tcount((size_t)n, 0);
     struct CRec { int32_t x, i, j; };
     struct Move { uint64_t key; int32_t v; };
@@ -215,12 +173,12 @@ int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const doubl
         // ---- P1: prepare (thread per candidate) ----
         for (int32_t i = 0; i < nc; ++i) { int32_t v = cand[i].v, src = cand[i].src; cand_prepare(A, v, cand[i]); cand[i].src = src; batch_pos[v] = i; }
         // ---- P1b: dependence; Pmax ----
-        int32_t Pmax = nc;
+        int32_t Pmax = nc; int Pwhy = 5;
         for (int32_t i = 0; i < nc; ++i) {
             Cand& C = cand[i];
             bool bad = (C.flags & (CF_BIG | CF_DUP)) != 0;
             if (!bad) for (int32_t j = 0; j < C.m; ++j) { int32_t bp = batch_pos[C.e[j].nbr]; if (bp >= 0 && bp < i) { bad = true; break; } }
-            if (bad) { Pmax = std::min(Pmax, i); }
+            if (bad && i < Pmax) { Pmax = i; Pwhy = (C.flags & CF_BIG) ? 1 : (C.flags & CF_DUP) ? 2 : 0; }
         }
         auto consume = [&](int32_t P) {   // candidates [0,P) leave the queue
             if (!use_pq) return;
@@ -231,11 +189,13 @@ int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const doubl
         auto cleanup = [&]() { for (int32_t i = 0; i < nc; ++i) batch_pos[cand[i].v] = -1; };
         if (Pmax == 0) {
             // candidate 0 needs the single-vertex path
+            ++why[Pwhy];
             ++singles;
             consume(1);
             cleanup();
             if (order_out) order_out[npop] = cand[0].v;
             ++npop;
+            { int32_t l0 = serial_gather(A, cand[0].v, S.B, S.cap); single_len += l0; if (l0 > 384) { ++single_gt384; single_gt384_len += l0; } if (l0 > single_max) single_max = l0; }
             int rc = serial_eliminate(A, G, S.B, S.cap, cand[0].v, done + 1);
             if (rc) return rc;
             done += 1;
@@ -287,18 +247,20 @@ int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const doubl
         int32_t P = Pmax;
         for (int32_t i = 0; i < Pmax; ++i) {
             Cand& C = cand[i];
-            if (C.flags & CF_COMPLEX) { P = std::min(P, i); break; }
+            if (C.flags & CF_COMPLEX) { P = std::min(P, i); Pwhy = 3; break; }
             bool pre = false;
             if (use_pq) for (int32_t j = 0; j < C.m; ++j) { TRes& R = ent_tres(C.e[j]); if (R.mv >= 0 && pq_list_of(R.key_after, G.n) <= G.minlist) pre = true; }
-            if (pre) { P = std::min(P, i + 1); break; }
+            if (pre) { if (i + 1 < P) Pwhy = 4; P = std::min(P, i + 1); break; }
         }
         for (int32_t i = 0; i < Pmax; ++i) for (int32_t j = 0; j < cand[i].m; ++j) tcount[cand[i].e[j].nbr] = 0;
+        ++why[Pwhy];
         if (P == 0) {
             ++singles;
             consume(1);
             cleanup();
             if (order_out) order_out[npop] = cand[0].v;
             ++npop;
+            { int32_t l0 = serial_gather(A, cand[0].v, S.B, S.cap); single_len += l0; if (l0 > 384) { ++single_gt384; single_gt384_len += l0; } if (l0 > single_max) single_max = l0; }
             int rc = serial_eliminate(A, G, S.B, S.cap, cand[0].v, done + 1);
             if (rc) return rc;
             done += 1;
@@ -321,7 +283,7 @@ int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const doubl
         std::sort(all.begin(), all.end(), [](const CRec& p, const CRec& q) { return p.x != q.x ? p.x < q.x : p.i < q.i; });
         // slots for pushes, stored back into a side table
         std::vector<std::vector<int32_t>> pslot((size_t)P);
-        for (int32_t i = 0; i < P; ++i) pslot[i].assign(BCAP, -1);
+        for (int32_t i = 0; i < P; ++i) pslot[i].assign(BC, -1);
         for (size_t q = 0; q < all.size(); ++q) {
             Cand& C = cand[all[q].i];
             int32_t x = all[q].x, j = all[q].j;
@@ -377,8 +339,73 @@ int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const doubl
         cleanup();
         done += P;
     }
-    if (stats_out) { stats_out[0] = rounds; stats_out[1] = singles; stats_out[2] = contended_total; }
+    if (stats_out) { stats_out[0] = rounds; stats_out[1] = singles; stats_out[2] = contended_total; for (int q = 0; q < 6; ++q) stats_out[3 + q] = why[q]; stats_out[9] = single_len; stats_out[10] = single_gt384; stats_out[11] = single_gt384_len; stats_out[12] = single_max; }
     return S.finish(nelim, npop, order_out, out, out_rows);
+}
+
+extern "C" {
+
+// std_sort_emul permutation of doubles: perm_out[i] = original index ending at i.
+void mirror_sort_perm(const double* keys, int64_t n, int desc, int64_t* perm_out) {
+    std::vector<SRec> r((size_t)n);
+    for (int64_t i = 0; i < n; ++i) { r[i].key = keys[i]; r[i].idx = (int32_t)i; r[i].aux = 0; }
+    if (desc) std_sort_emul<true>(r.data(), (int)n); else std_sort_emul<false>(r.data(), (int)n);
+    for (int64_t i = 0; i < n; ++i) perm_out[i] = r[i].idx;
+}
+
+// n <= 32: the stack-free variant used for batch candidates, on the (key,index) proxy view
+void mirror_sort_perm_small(const double* keys, int64_t n, int desc, int64_t* perm_out) {
+    Cand C;
+    for (int64_t i = 0; i < n; ++i) { C.e[i].aux = keys[i]; C.ksel[i] = (uint8_t)i; }
+    KIArr arr; arr.e = C.e; arr.ix = C.ksel;
+    if (desc) gs_std_sort_small<KI>(arr, (int)n, KIGreater()); else gs_std_sort_small<KI>(arr, (int)n, KILess());
+    for (int64_t i = 0; i < n; ++i) perm_out[i] = C.ksel[i];
+}
+
+void mirror_heapsort_perm(const double* keys, int64_t n, int desc, int64_t* perm_out) {
+    std::vector<SRec> r((size_t)n);
+    for (int64_t i = 0; i < n; ++i) { r[i].key = keys[i]; r[i].idx = (int32_t)i; r[i].aux = 0; }
+    if (desc) ss_heap_sort<true>(r.data(), 0, (int)n); else ss_heap_sort<false>(r.data(), 0, (int)n);
+    for (int64_t i = 0; i < n; ++i) perm_out[i] = r[i].idx;
+}
+
+// Coalesced, symmetric COO in (row[], col[], w[]) -> Schur complement rows,
+// sequential driver.  Single graph. Returns status; *out malloc'd (m,3).
+int mirror_approx_chol(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
+                       int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots,
+                       double** out, int64_t* out_rows, int64_t* order_out) {
+    Setup S;
+    S.build(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots);
+    int64_t nelim = std::min<int64_t>(t, n - 1);
+    if (nelim < 0) nelim = 0;
+    int64_t npop = 0;
+    for (int64_t e1 = 1; e1 <= nelim; ++e1) {
+        int32_t v = (o_v == OV_RANDOM) ? (int32_t)S.perm_l[n - e1] : pq_pop(S.A, S.G);
+        if (order_out) order_out[npop] = v;
+        ++npop;
+        int rc = serial_eliminate(S.A, S.G, S.B, S.cap, v, e1);
+        if (rc) return rc;
+    }
+    return S.finish(nelim, npop, order_out, out, out_rows);
+}
+
+// stats_out: [0] rounds, [1] single-vertex fallbacks, [2] contended targets, [3..8] what ended the rounds
+// (adjacent candidate, long column, multi-edge, complex key, pre-empting move, nothing).
+int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
+                             int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t Bsz,
+                             double** out, int64_t* out_rows, int64_t* order_out, int64_t* stats_out) {
+    int64_t st[13];
+    int rc = mirror_batch_impl<32>(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots, Bsz, out, out_rows, order_out, st);
+    if (stats_out) for (int q = 0; q < 3; ++q) stats_out[q] = st[q];
+    return rc;
+}
+
+// same with the candidate capacity of the kernel variant (32 or 64) and the full statistics (13 values: + singles: total length, count and total length of those over 384 entries, max)
+int mirror_approx_chol_batch_bc(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
+                                int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t Bsz,
+                                int32_t bc, double** out, int64_t* out_rows, int64_t* order_out, int64_t* stats_out) {
+    if (bc == 64) return mirror_batch_impl<64>(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots, Bsz, out, out_rows, order_out, stats_out);
+    return mirror_batch_impl<32>(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots, Bsz, out, out_rows, order_out, stats_out);
 }
 
 void mirror_free(double* p) { std::free(p); }

@@ -96,7 +96,7 @@ def test_device_data_structures_match_oracle(host_mirror, o_v, o_n):
         assert np.array_equal(a, b), name
 
 
-def _mirror_batch(lib, ei, w, n, t, o_v, o_n, B, perm=None, seed=0):
+def _mirror_batch(lib, ei, w, n, t, o_v, o_n, B, perm=None, seed=0, bc=32):
     E = ei.shape[1]
     row = np.ascontiguousarray(ei[0])
     col = np.ascontiguousarray(ei[1])
@@ -104,14 +104,14 @@ def _mirror_batch(lib, ei, w, n, t, o_v, o_n, B, perm=None, seed=0):
     out = ctypes.POINTER(ctypes.c_double)()
     rows = ctypes.c_int64()
     order = np.full(max(n, 1), -1, dtype=np.int64)
-    stats = np.zeros(4, dtype=np.int64)
+    stats = np.zeros(13, dtype=np.int64)
     p = np.ascontiguousarray(perm, dtype=np.int64) if perm is not None else None
-    lib.mirror_approx_chol_batch.restype = ctypes.c_int
-    rc = lib.mirror_approx_chol_batch(
+    lib.mirror_approx_chol_batch_bc.restype = ctypes.c_int
+    rc = lib.mirror_approx_chol_batch_bc(
         ctypes.c_void_p(row.ctypes.data), ctypes.c_void_p(col.ctypes.data), ctypes.c_void_p(w.ctypes.data),
         ctypes.c_int64(E), ctypes.c_int64(n), ctypes.c_int64(t), oracle.O_V[o_v], oracle.O_N[o_n],
         ctypes.c_void_p(p.ctypes.data) if p is not None else None, ctypes.c_uint64(seed), ctypes.c_int32(4 * E + 64),
-        ctypes.c_int32(B), ctypes.byref(out), ctypes.byref(rows), ctypes.c_void_p(order.ctypes.data),
+        ctypes.c_int32(B), ctypes.c_int32(bc), ctypes.byref(out), ctypes.byref(rows), ctypes.c_void_p(order.ctypes.data),
         ctypes.c_void_p(stats.ctypes.data))
     assert rc == 0
     m = rows.value
@@ -131,7 +131,7 @@ def test_batch_rounds_equal_sequential_order(host_mirror, o_v, o_n):
         for t in sorted({1, n // 2, n - 1}):
             for wts in (None, sym_weights(ei, n, 5)):
                 a, oa = oracle.approximate_cholesky(ei, wts, n, t, o_v, o_n, perm=perm, shuffle_seed=3, return_order=True)
-                for B in (1, 7, 128):
-                    b, ob, _ = _mirror_batch(host_mirror, ei, wts, n, t, o_v, o_n, B, perm=perm, seed=3)
-                    assert np.array_equal(oa, ob), (name, t, B)
-                    assert a.shape == b.shape and np.array_equal(a, b), (name, t, B)
+                for B, bc in ((1, 32), (7, 32), (128, 32), (64, 64)):   # 64-slot candidates: the o_v="random" kernel variant
+                    b, ob, _ = _mirror_batch(host_mirror, ei, wts, n, t, o_v, o_n, B, perm=perm, seed=3, bc=bc)
+                    assert np.array_equal(oa, ob), (name, t, B, bc)
+                    assert a.shape == b.shape and np.array_equal(a, b), (name, t, B, bc)

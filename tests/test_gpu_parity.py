@@ -57,7 +57,7 @@ def test_wave_parallel_std_sort_matches_libstdcxx(ops):
     rng = np.random.RandomState(0)
     arrays = []
     for trial in range(1500):
-        n = int(rng.choice([1, 2, 15, 16, 17, 18, 31, 32, 33, 40, 63, 64, 65, 100, 127, 128, 129, 257, 400, 512]))
+        n = int(rng.choice([1, 2, 15, 16, 17, 18, 24, 31, 32, 33, 40, 48, 56, 63, 64, 65, 100, 127, 128, 129, 257, 400, 512]))
         kind = trial % 6
         if kind == 0:
             k = np.ones(n)
@@ -77,13 +77,13 @@ def test_wave_parallel_std_sort_matches_libstdcxx(ops):
     keys = torch.from_numpy(np.concatenate(arrays)).cuda()
     offs_t = torch.from_numpy(offs).cuda()
     lib, h = ops._handle(torch.device("cuda", 0))
-    for desc in (0, 1):
+    for desc in (0, 1, 2, 3):   # bit 0: descending; bit 1: arrays of <= 64 elements go through the register-resident variant
         out = torch.empty(int(offs[-1]), dtype=torch.int32, device="cuda")
         rc = lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr())
         assert rc == 0
         got = out.cpu().numpy()
         for a_i, k in enumerate(arrays):
-            exp = oracle.stdsort_perm(k, bool(desc))
+            exp = oracle.stdsort_perm(k, bool(desc & 1))
             assert np.array_equal(got[offs[a_i]:offs[a_i + 1]], exp), (a_i, len(k), desc)
 
 
