@@ -654,9 +654,10 @@ struct CandT : CandPad<BC> {
     int32_t cp1;      // colptr[v+1]
     int32_t acnt;     // appended entries
     int32_t ext;      // slots to read (appended + CSR), dead ones included
+    int32_t nkill;    // merged multi-edges (o_v = random, 64-slot form): e[m .. m+nkill) hold the twins that die (:289)
     int32_t cb[BC <= 32 ? 3 : 4];   // bases of the appended chunks
     int64_t draw0;    // first uniform
-};   // 856 B (BC=32) / 1672 B (BC=64): word strides 214 / 418 share only a factor 2 with the 64 LDS banks
+};   // 864 B (BC=32) / 1680 B (BC=64): word strides 216 / 420
 typedef CandT<BCAP> Cand;
 
 RLAP_HD TRes& ent_tres(Ent& e) { return e.res; }
@@ -700,11 +701,17 @@ RLAP_HD void cand_order_index(const Arrays& A, CT& C) {
     C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
 }
 
+// Multi-edges inside a batch candidate: merged in place for o_v = random with 64-slot candidates (every
+// fourth vertex met in random order on small dense graphs has one); the PQ orders send them to the
+// single-vertex path, where the DegreePQDec per merged entry (:291) is replayed.
+template <class CT>
+RLAP_HD bool cand_merges_multi_edges(const Arrays& A) { return CT::CAP == 64 && A.o_v == OV_RANDOM; }
+
 // Candidate preparation in three steps so the loads can be spread over all
 // threads: cand_meta (one per candidate), cand_load (one per slot), cand_finish.
 template <class CT>
 RLAP_HD void cand_meta(const Arrays& A, int32_t v, CT& C) {
-    C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0;
+    C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0; C.nkill = 0;
     int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
     int32_t acnt = A.app_cnt[v];
     C.cp1 = cp1; C.acnt = acnt; C.ext = (cp1 - cp0) + acnt;
@@ -740,7 +747,22 @@ RLAP_HD void cand_finish(const Arrays& A, CT& C) {
     }
     C.m = len;
     gs_std_sort<Ent>(C.e, len, EntLessNbr());
-    for (int32_t i = 1; i < len; ++i) if (C.e[i].nbr == C.e[i - 1].nbr) { C.flags = CF_DUP; return; }
+    if (cand_merges_multi_edges<CT>(A)) {
+        // merge equal ids in sorted order (:278-293): the first keeps its slot and twin and takes the sum,
+        // the twins of the others die at commit (no PQ in this mode, so nothing else to replay)
+        int32_t mm = 0, nk = 0;
+        int32_t kill[CT::CAP];
+        for (int32_t i = 0; i < len; ++i) {
+            if (mm == 0 || C.e[i].nbr != C.e[mm - 1].nbr) { if (mm != i) C.e[mm] = C.e[i]; ++mm; }
+            else { C.e[mm - 1].val += C.e[i].val; kill[nk++] = C.e[i].twin; }
+        }
+        for (int32_t q = 0; q < nk; ++q) C.e[mm + q].twin = kill[q];
+        C.nkill = nk;
+        len = mm;
+        C.m = len;
+    } else {
+        for (int32_t i = 1; i < len; ++i) if (C.e[i].nbr == C.e[i - 1].nbr) { C.flags = CF_DUP; return; }
+    }
     if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
         uint64_t kb = keyed_order_base(A.shuffle_seed, C.v, 0);
         for (int32_t i = 0; i < len; ++i) C.e[i].aux = keyed_order_dkey(kb, C.e[i].nbr);

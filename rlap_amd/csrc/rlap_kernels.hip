@@ -949,6 +949,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
     constexpr int BATCH = SLOTS / BC;
     typedef CandT<BC> Cand;
     typedef BatchLdsT<BC> BatchLds;
+    constexpr bool MERGE = (BC == 64 && OV == OV_RANDOM);           // multi-edges merged inside the candidate (rlap_core.h::cand_merges_multi_edges)
     constexpr int GSH = 64 - BC;                                  // lane & GSH = first lane of my group
     constexpr uint64_t GMASK = BC == 64 ? ~0ull : 0xFFFFFFFFull;   // a group's part of a 64-bit ballot
     Arrays A = A_in;
@@ -1139,9 +1140,10 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             // One half-wave = one candidate.  A column without appended entries whose CSR segment is still
             // sorted is read in descending id, so its rank is a popcount of the live mask; others loop.
             int32_t rk[PASSES];
+            bool merge_k[PASSES];
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                rk[k] = -1;
+                rk[k] = -1; merge_k[k] = false;
                 if (__ballot(la[k]) == 0ull) continue;   // wave-uniform: nothing left in this pass for this wave
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, e = idx % BCAP;
@@ -1158,20 +1160,61 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     if (C.acnt == 0 && hbad == 0) {
                         if (live) rk[k] = __popcll(half & ~((2ull << e) - 1ull));
                         if (e == 0) C.m = __popcll(half);
-                    } else if (live) {
-                        const int32_t ext = C.ext, me = ln[k];
-                        int32_t r = 0, nlive = 0;
-                        bool dup = false;
-                        for (int32_t q = 0; q < ext; ++q) {
-                            bool lq = C.e[q].val > 0;
-                            int32_t nq = C.e[q].nbr;
-                            nlive += lq ? 1 : 0;
-                            r += (lq && nq < me) ? 1 : 0;
-                            dup |= (lq && nq == me && q != e);
+                    } else if (!MERGE) {
+                        if (live) {
+                            const int32_t ext = C.ext, me = ln[k];
+                            int32_t r = 0, nlive = 0;
+                            bool dup = false;
+                            for (int32_t q = 0; q < ext; ++q) {
+                                bool lq = C.e[q].val > 0;
+                                int32_t nq = C.e[q].nbr;
+                                nlive += lq ? 1 : 0;
+                                r += (lq && nq < me) ? 1 : 0;
+                                dup |= (lq && nq == me && q != e);
+                            }
+                            rk[k] = r;
+                            if (dup) atomicOr(&C.flags, CF_DUP);
+                            if (r == 0) C.m = nlive;
                         }
-                        rk[k] = r;
-                        if (dup) atomicOr(&C.flags, CF_DUP);
-                        if (r == 0) C.m = nlive;
+                    } else {
+                        // one wave = this candidate.  Multi-edges are merged here (no PQ to replay in this mode): the
+                        // position std::sort by id gives every live entry (stable rank up to 16 entries, the
+                        // introsort restatement above), then merge_k[] below folds equal ids.
+                        const int32_t ext = C.ext, me = ln[k];
+                        int32_t r = 0, eqb = 0;
+                        bool dup = false;
+                        if (live) {
+                            for (int32_t q = 0; q < ext; ++q) {
+                                bool lq = C.e[q].val > 0;
+                                int32_t nq = C.e[q].nbr;
+                                r += (lq && nq < me) ? 1 : 0;
+                                eqb += (lq && nq == me && q < e) ? 1 : 0;
+                                dup |= (lq && nq == me && q != e);
+                            }
+                        }
+                        const int32_t nlive = __popcll(half);
+                        const bool anydup = __ballot(live && dup) != 0ull;
+                        if (!anydup) {
+                            if (live) rk[k] = r;
+                        } else if (nlive <= 16) {
+                            if (live) rk[k] = r + eqb;
+                            merge_k[k] = true;
+                        } else {
+                            int32_t* tmp = L.pslot + (tid >> 6) * 256;   // pslot is not live before the commit
+                            if (live) tmp[144 + __popcll(half & lanemask_lt(lane))] = lane;   // gather order = traversal order
+                            WAVE_SYNC();
+                            const int src = lane < nlive ? tmp[144 + lane] : 0;
+                            double key = (double)__shfl(me, src);
+                            int idx = src, pos = lane;
+                            const bool ok = wave_sort64<false>(key, idx, nlive, lane, tmp, &pos);
+                            WAVE_SYNC();
+                            if (lane < nlive) tmp[144 + idx] = pos;
+                            WAVE_SYNC();
+                            if (ok) { if (live) rk[k] = tmp[144 + lane]; merge_k[k] = true; }
+                            else if (lane == 0) atomicOr(&C.flags, CF_DUP);   // depth limit hit: single-vertex path
+                            WAVE_SYNC();
+                        }
+                        if (lane == 0) C.m = nlive;
                     }
                 }
             }
@@ -1186,6 +1229,39 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     Ent& E = C.e[rk[k]];
                     E.val = lv[k]; E.nbr = ln[k]; E.twin = lt[k];
                     E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v, 0), ln[k]) : lv[k];
+                }
+            }
+            if (MERGE) {
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) {
+                    if (!merge_k[k]) continue;   // wave-uniform
+                    WAVE_SYNC();
+                    Cand& C = L.cand[k * NWAVE + (tid >> 6)];
+                    const int32_t nl = C.m;
+                    const bool act = lane < nl;
+                    const int32_t nb = act ? C.e[lane].nbr : -1;
+                    const int32_t tw = act ? C.e[lane].twin : 0;
+                    double val = act ? C.e[lane].val : 0.0;
+                    const int32_t nbprev = __shfl_up(nb, 1);
+                    const bool head = act && (lane == 0 || nb != nbprev);
+                    const uint64_t hm = __ballot(head), lt = lanemask_lt(lane);
+                    const int32_t m = __popcll(hm);
+                    if (head) {   // the sum runs in sorted order (:284)
+                        const uint64_t above = (lane == 63) ? 0ull : (hm >> (lane + 1));
+                        const int nexthead = above ? (lane + 1 + __builtin_ctzll(above)) : nl;
+                        for (int q = lane + 1; q < nexthead; ++q) val += C.e[q].val;
+                    }
+                    const int32_t x = __popcll(hm & lt);
+                    const int32_t y = __popcll(__ballot(act && !head) & lt);
+                    WAVE_SYNC();
+                    if (head) {
+                        Ent& E = C.e[x];
+                        E.val = val; E.nbr = nb; E.twin = tw;
+                        E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v, 0), nb) : val;
+                    } else if (act) {
+                        C.e[m + y].twin = tw;   // dies at commit (:289)
+                    }
+                    if (lane == 0) { C.m = m; C.nkill = nl - m; }
                 }
             }
             PHASE_STAMP(15);
@@ -1469,6 +1545,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             if (use_pq) A.pqpos[C.v] = -2;
             // the edge to the last neighbour (or to the coarsening target) dies (:429-430 | :880-881)
             if (C.m >= 1) A.e_val[C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin] = 0;
+            if (MERGE) for (int32_t q = 0; q < C.nkill; ++q) A.e_val[C.e[C.m + q].twin] = 0;   // merged multi-edges (:289)
         }
         // targets touched by one candidate only: one thread per (candidate, target); two passes so that
         // all loads are in flight together and the pool is bumped once per round

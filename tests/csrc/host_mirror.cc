@@ -331,6 +331,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
                 }
                 if (m >= 1) A.e_val[C.e[m - 1].twin] = 0;
             }
+            for (int32_t q = 0; q < C.nkill; ++q) A.e_val[C.e[m + q].twin] = 0;   // merged multi-edges (:289)
             G.n_draws += C.ndraw;
         }
         // PQ pushes in (bucket, op) order
