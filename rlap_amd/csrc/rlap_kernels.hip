@@ -491,6 +491,108 @@ __device__ __forceinline__ bool wave_sort64(double& key, int& idx, const int n, 
     return true;
 }
 
+// The same for groups of BC lanes (BC = 32: two candidates per wave sort side by side).  `n` and `want`
+// are uniform inside a group; the groups run the introsort loop as one predicated state machine (a group
+// that has nothing left idles through the others' partitions).  Scratch: 2*(BC+2)+12 ints per group.
+// Returns (per group) false when the depth limit was hit.
+template <bool DESC, int BC>
+__device__ __forceinline__ bool group_sort(double& key, int& idx, const int n, const bool want, const int lane, int32_t* tmp_wave, int* pos) {
+    auto less = [](double x, double y) { return DESC ? (x > y) : (x < y); };
+    constexpr int TU = BC + 2;
+    const int gl = lane & (BC - 1), gbase = lane & ~(BC - 1);
+    int32_t* tmpu = tmp_wave + (lane / BC) * (2 * TU + 12);
+    int32_t* tmpd = tmpu + TU;
+    int32_t* stk = tmpd + TU;
+    const uint64_t gmask = (BC == 64) ? ~0ull : (0xFFFFFFFFull << gbase);
+    const uint64_t lt = lanemask_lt(lane) & gmask;
+    const uint64_t gt = ((lane == 63) ? 0ull : (~0ull << (lane + 1))) & gmask;
+    uint64_t segmask = 0ull;   // group-relative positions where a <=16-element segment starts
+    bool fail = false;
+    int first = 0, last = want ? n : 0, sp = 0;
+    int depth = n > 1 ? 2 * (31 - __clz(n)) : 0;
+    bool done = !(want && n > 16);
+    if (done) segmask = 1ull;
+    while (true) {
+        if (!done && last - first <= 16) {   // this segment is left to the final insertion sort
+            segmask |= 1ull << first;
+            if (sp == 0) done = true;
+            else { --sp; first = stk[3 * sp]; last = stk[3 * sp + 1]; depth = stk[3 * sp + 2]; }   // pushed segments are > 16 long
+        }
+        if (!done && depth == 0) { fail = true; done = true; }
+        if (__ballot(!done) == 0ull) break;
+        const bool act = !done;
+        depth -= act ? 1 : 0;
+        // __move_median_to_first(first, first+1, mid, last-1)
+        const int ia = act ? first + 1 : 0, ib = act ? first + (last - first) / 2 : 0, ic = act ? last - 1 : 0, fi = act ? first : 0;
+        const double ka = __shfl(key, gbase + ia), kb = __shfl(key, gbase + ib), kc = __shfl(key, gbase + ic);
+        int pick;
+        if (less(ka, kb)) {
+            if (less(kb, kc)) pick = ib;
+            else if (less(ka, kc)) pick = ic;
+            else pick = ia;
+        } else if (less(ka, kc)) pick = ia;
+        else if (less(kb, kc)) pick = ic;
+        else pick = ib;
+        {
+            const double kf = __shfl(key, gbase + fi), kp = __shfl(key, gbase + pick);
+            const int xf = __shfl(idx, gbase + fi), xp = __shfl(idx, gbase + pick);
+            if (act) {
+                if (gl == first) { key = kp; idx = xp; }
+                else if (gl == pick) { key = kf; idx = xf; }
+            }
+        }
+        const double pv = __shfl(key, gbase + fi);
+        const bool inr = act && gl > first && gl < last;
+        const bool su = inr && !less(key, pv);
+        const bool sd = inr && !less(pv, key);
+        const uint64_t mu = __ballot(su) & gmask, md = __ballot(sd) & gmask;
+        const int nu = popc64(mu), nd = popc64(md);
+        const int ru = popc64(mu & lt), rd = popc64(md & gt);
+        if (su) tmpu[ru] = gl;
+        if (sd) tmpd[rd] = gl;
+        if (act && gl == 0) tmpd[nd] = first;   // the pivot itself stops the down-scan
+        WAVE_SYNC();
+        const int tmax = nu < nd ? nu : nd;
+        const bool okp = act && (gl < tmax) && (tmpu[gl] < tmpd[gl]);
+        const int k = popc64(__ballot(okp) & gmask);   // a prefix of the pairs
+        int partner = gl;
+        if (su && ru < k) partner = tmpd[ru];
+        else if (sd && rd < k) partner = tmpu[rd];
+        int cu = 0x7FFFFFFF, cd = 0x7FFFFFFF;
+        if (act && k < nu) cu = tmpu[k];
+        if (act && k > 0) cd = tmpd[k - 1];
+        const int cut = cu < cd ? cu : cd;
+        WAVE_SYNC();
+        key = __shfl(key, gbase + partner);
+        idx = __shfl(idx, gbase + partner);
+        if (act) {
+            if (last - cut > 16) {
+                if (gl == 0) { stk[3 * sp] = cut; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth; }
+                ++sp;
+            } else {
+                segmask |= 1ull << cut;
+            }
+            last = cut;
+        }
+        WAVE_SYNC();
+    }
+    // final insertion sort == stable sort of every marked segment: my rank inside my segment
+    const int l2 = gl < n ? gl : 0;
+    const uint64_t below = segmask & ((2ull << l2) - 1ull);
+    const int s0 = 63 - __builtin_clzll(below | 1ull);
+    const uint64_t above = (l2 == 63) ? 0ull : (segmask >> (l2 + 1));
+    const int e0 = above ? (l2 + 1 + __builtin_ctzll(above)) : n;
+    int cnt = 0;
+    for (int q = 0; q < 16; ++q) {
+        const int p = s0 + q;
+        const double kq = __shfl(key, gbase + (p < BC ? p : BC - 1));
+        const bool in = p < e0 && p != gl;
+        cnt += (in && (less(kq, key) || (!less(key, kq) && p < gl))) ? 1 : 0;
+    }
+    *pos = s0 + cnt;
+    return !fail;
+}
+
 struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key < y.key; } };
 struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
 
@@ -1340,12 +1442,38 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                         C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
                     }
                 }
-            } else if (tid < nc) {
-                Cand& C = L.cand[tid];
-                if (!(C.flags & (CF_BIG | CF_DUP | CF_READY))) {
-                    const int32_t m = C.m;
-                    if (m > 16 && (C.flags & CF_TIE) && (C.flags & CF_NEQ)) { Arrays A3 = A; cand_order_index_call(A3, C); }
-                    C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
+            } else {
+                // half a wave = one candidate: the same with two independent sorts per wave
+                __syncthreads();   // rank writes of ksel above vs. the sort's own
+                int32_t* tmp = L.pslot + (tid >> 6) * 256;   // pslot is not live before the commit
+#pragma unroll 1
+                for (int k = 0; k < PASSES; ++k) {
+                    const int32_t i = (k * NT + tid) / BCAP;
+                    const int gl = lane & (BC - 1);
+                    bool want = false;
+                    int32_t m = 0;
+                    if (i < nc) {
+                        const int32_t fl = L.cand[i].flags;
+                        m = L.cand[i].m;
+                        want = !(fl & (CF_BIG | CF_DUP | CF_READY)) && m > 16 && (fl & CF_TIE) && (fl & CF_NEQ);
+                    }
+                    if (__ballot(want) == 0ull) continue;
+                    Cand& C = L.cand[i < nc ? i : 0];
+                    double key = (want && gl < m) ? C.e[gl].aux : 0.0;
+                    int idx = gl, pos = gl;
+                    const bool ok = desc ? group_sort<true, BC>(key, idx, m, want, lane, tmp, &pos) : group_sort<false, BC>(key, idx, m, want, lane, tmp, &pos);
+                    if (want) {
+                        if (ok) { if (gl < m) C.ksel[pos] = (uint8_t)idx; }
+                        else if (gl == 0) { Arrays A3 = A; cand_order_index_call(A3, C); }
+                    }
+                    WAVE_SYNC();
+                }
+                if (tid < nc) {
+                    Cand& C = L.cand[tid];
+                    if (!(C.flags & (CF_BIG | CF_DUP | CF_READY))) {
+                        const int32_t m = C.m;
+                        C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
+                    }
                 }
             }
             __syncthreads();
@@ -1892,6 +2020,20 @@ __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict
         for (int q = lane; q < n; q += 64) { rec[q].key = keys[o + q]; rec[q].idx = q; rec[q].aux = 0; }
         __syncthreads();
         WaveSortPtrs WP = {W.ulist, W.dlist, W.segmark, W.stk};
+        if (desc & 4) {   // half-wave variant: this block's wave sorts arrays 2*arr and 2*arr+1 side by side (those of <= 32 elements)
+            const int32_t a2 = 2 * arr + (lane >> 5);
+            const int gl = lane & 31;
+            int32_t o2 = 0, n2 = 0;
+            if (a2 < narr) { o2 = offs[a2]; n2 = offs[a2 + 1] - o2; }
+            const bool want = a2 < narr && n2 <= 32 && n2 >= 1;
+            double key = (want && gl < n2) ? keys[o2 + gl] : 0.0;
+            int idx = gl, pos = gl;
+            bool ok = (desc & 1) ? group_sort<true, 32>(key, idx, n2, want, lane, tmp64, &pos) : group_sort<false, 32>(key, idx, n2, want, lane, tmp64, &pos);
+            if (want && gl < n2) perm_out[o2 + (ok ? pos : gl)] = ok ? idx : -1;
+            __syncthreads();
+            if (2 * arr + 2 >= narr) break;
+            continue;
+        }
         if ((desc & 2) && n <= 64) {   // register-resident variant (batch candidates of the 64-slot kernel)
             double key = lane < n ? rec[lane].key : 0.0;
             int idx = lane, pos = lane;
