@@ -651,6 +651,8 @@ __device__ __forceinline__ int32_t alloc_in_column(const Arrays& A, int32_t& a, 
     return s;
 }
 
+__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Single-vertex path, executed by ONE wave (columns up to ECAP entries, multi-edges, any key range).
 __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
                                int32_t acnt, int32_t abase) {
@@ -941,6 +943,191 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 
 
 // ---------------------------------------------------------------------------
+// Single-vertex path for columns beyond ECAP entries, o_v = random (hubs met early in a random order;
+// no PQ to replay).  One wave; the sort records, the stop lists and afterwards the cumulative weights live
+// in the workgroup's LDS (the batch round's storage is free while a single vertex is eliminated), the column
+// itself in the graph's global scratch.  Every step is O(len/64) or the O(len log len / 64) sort; the only
+// lane-serial parts are the two floating-point recurrences, whose order of operations is the result.
+// Returns false (nothing changed) when the column does not fit: the caller falls back to the sequential form.
+// ---------------------------------------------------------------------------
+constexpr int BIGE = 7168;
+struct BigElimLds {
+    union {
+        SRec rec[BIGE];
+        struct { double cum[BIGE]; double newv[BIGE]; } c;
+    };
+    uint16_t ulist[BIGE + 2];
+    uint16_t dlist[BIGE + 2];
+    uint32_t segmark[BIGE / 32 + 2];
+    int32_t stk[3 * 48];
+    int32_t tmp[64];
+};
+
+__device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, BigElimLds& L, const ColBuf& B, int32_t cap, int32_t v,
+                                                int32_t cp0, int32_t cp1, int32_t acnt, int32_t abase) {
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt(lane);
+    if (cap > BIGE) cap = BIGE;
+
+    // ---- gather live entries in the reference's traversal order (:616-639) ----
+    int len0 = 0;
+    {
+        int32_t idx = acnt - 1, base = abase;
+        int c = idx >= 0 ? chunk_of(idx) : 0;
+        while (idx >= 0) {
+            int32_t cs = chunk_start(c);
+            for (int32_t t0 = idx; t0 >= cs; t0 -= 64) {
+                int32_t t = t0 - lane;
+                bool valid = t >= cs;
+                int32_t s = base + 1 + (t - cs);
+                double val = 0; int32_t nb = 0, tw = 0;
+                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; tw = A.e_twin[s]; }
+                bool live = valid && val > 0;
+                uint64_t mask = __ballot(live);
+                int pos = len0 + popc64(mask & lt);
+                if (live && pos < cap) { B.a_slot[pos] = s; B.a_nbr[pos] = nb; B.a_val[pos] = val; B.a_twin[pos] = tw; }
+                len0 += popc64(mask);
+            }
+            int32_t prev = A.e_nbr[base];
+            idx = cs - 1; base = prev; --c;
+        }
+        for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
+            int32_t s = s0 - lane;
+            bool valid = s >= cp0;
+            double val = 0; int32_t nb = 0, tw = 0;
+            if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; tw = A.e_twin[s]; }
+            bool live = valid && val > 0;
+            uint64_t mask = __ballot(live);
+            int pos = len0 + popc64(mask & lt);
+            if (live && pos < cap) { B.a_slot[pos] = s; B.a_nbr[pos] = nb; B.a_val[pos] = val; B.a_twin[pos] = tw; }
+            len0 += popc64(mask);
+        }
+    }
+    if (len0 > cap) return false;
+    WAVE_SYNC();
+    const WaveSortPtrs WP = {L.ulist, L.dlist, L.segmark, L.stk};
+
+    // ---- sort by neighbour id (std::sort semantics, :641-644) ----
+    for (int i = lane; i < len0; i += 64) { L.rec[i].key = (double)B.a_nbr[i]; L.rec[i].idx = i; L.rec[i].aux = 0; }
+    WAVE_SYNC();
+    wave_std_sort<SRec>(L.rec, len0, SRecLessKey(), WP, lane);
+    WAVE_SYNC();
+
+    // ---- merge multi-edges (:646-659): group heads by ballot, the sum runs in sorted order ----
+    int m = 0;
+    for (int p0 = 0; p0 < len0; p0 += 64) {
+        const int p = p0 + lane;
+        const bool act = p < len0;
+        const int s = act ? L.rec[p].idx : 0;
+        const int32_t nb = act ? B.a_nbr[s] : -1;
+        const int32_t nbprev = (act && p > 0) ? B.a_nbr[L.rec[p - 1].idx] : -2;
+        const bool head = act && nb != nbprev;
+        const uint64_t mask = __ballot(head);
+        const int x = m + popc64(mask & lt);
+        if (head) {
+            double val = B.a_val[s];
+            for (int q = p + 1; q < len0 && B.a_nbr[L.rec[q].idx] == nb; ++q) val += B.a_val[L.rec[q].idx];
+            B.b_slot[x] = B.a_slot[s]; B.b_nbr[x] = nb; B.b_twin[x] = B.a_twin[s]; B.b_val[x] = val;
+        } else if (act) {
+            A.e_val[B.a_twin[s]] = 0;   // duplicate's twin dies (:655)
+        }
+        m += popc64(mask);
+    }
+    WAVE_SYNC();
+
+    // ---- order neighbours by o_n (:661-673) ----
+    if (A.o_n == ON_RANDOM) {
+        const uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
+        for (int i = lane; i < m; i += 64) { L.rec[i].key = keyed_order_dkey(kb, B.b_nbr[i]); L.rec[i].idx = i; }
+    } else {
+        for (int i = lane; i < m; i += 64) { L.rec[i].key = B.b_val[i]; L.rec[i].idx = i; }
+    }
+    WAVE_SYNC();
+    if (A.o_n == ON_DESC) wave_std_sort<SRec>(L.rec, m, SRecGreaterKey(), WP, lane);
+    else wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
+    WAVE_SYNC();
+    for (int j = lane; j < m; j += 64) {
+        const int x = L.rec[j].idx;
+        B.a_slot[j] = B.b_slot[x]; B.a_nbr[j] = B.b_nbr[x]; B.a_val[j] = B.b_val[x]; B.a_twin[j] = B.b_twin[x];
+    }
+    WAVE_SYNC();
+
+    // ---- cumulative weights + the f / colScale / wdeg recurrences (:728-779), in LDS over the sort records ----
+    double* cum = L.c.cum;
+    double* newv = L.c.newv;
+    for (int j = lane; j < m; j += 64) newv[j] = B.a_val[j];
+    WAVE_SYNC();
+    if (lane == 0) {
+        double csum = 0;
+        for (int j = 0; j < m; ++j) { csum += newv[j]; cum[j] = csum; }
+        double wdeg = csum, colScale = 1;
+        for (int j = 0; j < m - 1; ++j) {
+            double w = newv[j] * colScale;
+            double f = w / wdeg;
+            double omf = 1 - f;
+            newv[j] = f * omf * wdeg;
+            colScale = colScale * omf;
+            wdeg = wdeg * omf * omf;
+        }
+    }
+    WAVE_SYNC();
+    const double csum = m > 0 ? cum[m - 1] : 0.0;
+    const int64_t draws0 = G.n_draws;
+    const int ndraw = m > 1 ? m - 1 : 0;
+    if (draws0 + ndraw > A.rng_len) { if (lane == 0) G.status = ST_RNG_OVERFLOW; WAVE_SYNC(); return true; }
+
+    // ---- sample k for every position but the last (:747-756) ----
+    for (int j = lane; j < m - 1; j += 64) {
+        double u = A.rng[draws0 + j];
+        double cj = cum[j];
+        double r = u * (csum - cj) + cj;
+        B.ksel[j] = upper_index(cum, m, r);
+    }
+    WAVE_SYNC();
+
+    // ---- rewire (:766-776), 64 positions at a time in position order: lanes that drew the same target form a
+    //      group whose first lane hands out the target's next slots in lane (= position) order ----
+    int32_t status = 0;
+    for (int j0 = 0; j0 < m - 1; j0 += 64) {
+        const int j = j0 + lane;
+        const bool act = j < m - 1;
+        const int32_t k = act ? B.a_nbr[B.ksel[j]] : (-1 - lane);
+        uint64_t mymask = 0ull, rem = __ballot(act);
+        while (rem) {
+            const int l = __builtin_ctzll(rem);
+            const int32_t kk = __shfl(k, l);
+            const uint64_t same = __ballot(act && k == kk);
+            if (act && k == kk) mymask = same;
+            rem &= ~same;
+        }
+        if (act && lane == __builtin_ctzll(mymask)) {
+            int32_t a = ld_agent(&A.app_cnt[k]), chunk = ld_agent(&A.app_chunk[k]);
+            uint64_t mm = mymask;
+            while (mm) { const int l = __builtin_ctzll(mm); mm &= mm - 1; L.tmp[l] = alloc_in_column(A, a, chunk, &status); }
+            A.app_cnt[k] = a; A.app_chunk[k] = chunk;
+        }
+        __threadfence();
+        WAVE_SYNC();
+        if (act && status == 0) {
+            const int32_t s_r = B.a_twin[j], s_n = L.tmp[lane];
+            const double nw = newv[j];
+            A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
+            A.e_nbr[s_n] = B.a_nbr[j]; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+        }
+        WAVE_SYNC();
+        if (__ballot(status != 0) != 0ull) break;
+    }
+    if (__ballot(status != 0) != 0ull) { if (lane == 0) G.status = ST_POOL_OVERFLOW; WAVE_SYNC(); return true; }
+    if (lane == 0) {
+        if (m >= 1) A.e_val[B.a_twin[m - 1]] = 0;   // :791-792
+        G.n_draws = draws0 + ndraw;
+    }
+    WAVE_SYNC();
+    return true;
+}
+
+
+// ---------------------------------------------------------------------------
 // Batch kernel
 // ---------------------------------------------------------------------------
 constexpr int NT = 1024;      // threads per workgroup of the batch kernel (measured faster than 512 despite tighter registers)
@@ -968,7 +1155,9 @@ template <int BC>
 union ElimSharedT {
     BatchLdsT<BC> b;
     ElimLds e;
+    BigElimLds g;
 };
+static_assert(sizeof(BigElimLds) <= sizeof(BatchLdsT<64>) && sizeof(BigElimLds) <= sizeof(BatchLdsT<32>), "the long-column path borrows the batch round's LDS");
 
 // exclusive block scan over NT threads; returns exclusive prefix, *total = sum
 __device__ __noinline__ int block_excl_scan(int val, int* scratch, int* total) {
@@ -989,7 +1178,6 @@ __device__ __forceinline__ int block_rank(bool flag, int* scratch, int* total) {
     return block_excl_scan(flag ? 1 : 0, scratch, total);
 }
 
-__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // rewire stores of one push (preconditioner.cc:404-414)
 __device__ __forceinline__ void rewire_store(const Arrays& A, int32_t s_r, int32_t s_n, int32_t nbr_j, int32_t k, double nw) {
@@ -1650,7 +1838,12 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                 int32_t cp0 = A2.colptr[v0], cp1 = A2.colptr[v0 + 1];
                 int32_t acnt = A2.app_cnt[v0], abase = A2.app_chunk[v0];
                 if ((cp1 - cp0) + acnt > ECAP) {
-                    if (lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
+                    bool handled = false;
+                    if (OV == OV_RANDOM) {
+                        ColBuf Bf = S2.colbuf(G.scr_base);
+                        handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
+                    }
+                    if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
                 } else {
                     wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase);
                 }

@@ -145,6 +145,35 @@ def test_medium_ba_graphs(ops, n, m, o_v, o_n):
         assert_same(b, a, f"BA({n},{m}) {o_v}/{o_n} weighted={w is not None}")
 
 
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_long_columns_random_order(ops, o_n):
+    """o_v="random" meets hubs early: columns beyond the 64-slot batch candidates (wave path, <= 384 entries)
+    and beyond the wave path (long-column path, LDS sort records + global scratch), with multi-edges
+    created by earlier eliminations."""
+    cases = []
+    n = 1500
+    ei = star(n)
+    deg = np.bincount(ei[0], minlength=n)
+    hub = int(np.argmax(deg))
+    for pos in (0, 5, 700):          # the hub is popped first / after a few leaves / in the middle (pop = from the back)
+        rest = [v for v in np.random.RandomState(pos).permutation(n) if v != hub]
+        order = rest[:pos] + [hub] + rest[pos:]
+        cases.append((f"star{n}@{pos}", ei, n, np.array(order[::-1])))
+    n = 3000
+    ei = ba_graph(n, 40, 11)
+    deg = np.bincount(ei[0], minlength=n)
+    hubs = list(np.argsort(-deg)[:12])
+    rest = [v for v in np.random.RandomState(3).permutation(n) if v not in set(hubs)]
+    order = rest[:400] + hubs + rest[400:]      # 400 eliminations first: fill-in and multi-edges reach the hubs
+    cases.append(("BA3000_40 hubs", ei, n, np.array(order[::-1])))
+    for name, ei, n, perm in cases:
+        for w in (None, sym_weights(ei, n, 9)):
+            t = n // 2
+            a = oracle.approximate_cholesky(ei, w, n, t, "random", o_n, perm=perm, shuffle_seed=6)
+            b = gpu_call(ops, ei, w, n, t, "random", o_n, perm=perm, seed=6)
+            assert_same(b, a, f"{name} {o_n} {'unit' if w is None else 'weighted'}")
+
+
 def test_reference_unit_test_shape(ops):
     # reference tests/test_rlap.py:39-61: BA(100, 50), ones((1,E)) weights, t=50, random/asc
     n = 100
