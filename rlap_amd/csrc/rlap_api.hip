@@ -272,8 +272,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     ES.prof = nullptr;
     const char* prof_env = std::getenv("RLAP_PHASE_PROFILE");   // diagnostic only: per-phase clock sums of graph 0
     if (prof_env && prof_env[0] == '1') {
-        ENSURE(h->prof, 8 * 24);
-        HIPCHK(hipMemsetAsync(h->prof.p, 0, 8 * 24, s));
+        ENSURE(h->prof, 8 * 40);
+        HIPCHK(hipMemsetAsync(h->prof.p, 0, 8 * 40, s));
         ES.prof = h->prof.as<long long>();
     }
 
@@ -285,11 +285,13 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     HIPCHK(hipMemcpyAsync(gd.data(), h->gd_d.p, sizeof(GraphDesc) * G, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (ES.prof) {
-        long long pr[24];
+        long long pr[40];
         HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
         const char* names[19] = {"P0 select", "P1c4 permute", "P1b depend", "P2+P3 offsets+sample", "P4 replay", "single path", "P5b slots+contended", "moves sort", "pushes", "P1ab meta+loads", "P5a loads+scan+bump", "P5c rewire stores", "P1c1 rank", "P1c2d sync after R2", "P1c3 order-index", "P1c2a write pass (wave0)", "P1c2b sync after write", "P1c2c R2 pass (wave0)", "empty (cost of one stamp)"};
         std::fprintf(stderr, "[rlap phase profile] rounds=%lld singles=%lld (100 MHz ticks); shader clock over the kernel: %.0f MHz\n", pr[22], pr[23], pr[21] > 0 ? 100.0 * (double)pr[20] / (double)pr[21] : 0.0);
         for (int k = 0; k < 19; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
+        const char* wnames[9] = {"gather", "sort by id", "merge", "meta loads + order", "cumsum + recurrence", "sample", "replay + slots", "rewire", "pq commit"};
+        for (int k = 0; k < 9; ++k) std::fprintf(stderr, "  single/wave: %-20s %10.3f ms\n", wnames[k], pr[24 + k] / 1e5);
     }
     for (int64_t g = 0; g < G; ++g) {
         if (gd[g].status) {

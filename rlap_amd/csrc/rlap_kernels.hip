@@ -254,7 +254,7 @@ typedef WaveSortScratchT<SCAP> WaveSortScratch;
 struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; };
 
 template <class T, class Less>
-__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane) {
+__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane, T* obuf = nullptr) {
     struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
     if (n < 2) return;
     const uint64_t lt = lanemask_lt(lane);
@@ -361,6 +361,33 @@ __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int
         if (lane == 0) atomicOr(&W.segmark[first >> 5], 1u << (first & 31));
         (void)heap_sorted;
         WAVE_SYNC();
+    }
+    if (obuf) {
+        // final insertion sort == stable sort of every marked segment (<= 16 elements): one lane per ELEMENT
+        // computes its rank inside its segment and writes it to its place in obuf, then everything is copied back
+        for (int p = lane; p < n; p += 64) {
+            const int w = p >> 5;
+            const uint32_t here = W.segmark[w];
+            const uint32_t lowm = here & (0xFFFFFFFFu >> (31 - (p & 31)));
+            int s0;
+            if (lowm) s0 = w * 32 + 31 - __builtin_clz(lowm);
+            else { int w1 = w - 1; uint32_t bb = W.segmark[w1]; while (bb == 0u) { --w1; bb = W.segmark[w1]; } s0 = w1 * 32 + 31 - __builtin_clz(bb); }
+            const uint32_t highm = ((p & 31) == 31) ? 0u : (here & (0xFFFFFFFFu << ((p & 31) + 1)));
+            int e0 = n;
+            if (highm) e0 = w * 32 + __builtin_ctz(highm);
+            else { for (int w1 = w + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } } }
+            const T v = a[p];
+            int r = s0;
+            for (int q = s0; q < e0; ++q) {
+                const T x = a[q];
+                r += (q != p && (less(x, v) || (!less(v, x) && q < p))) ? 1 : 0;
+            }
+            obuf[r] = v;
+        }
+        WAVE_SYNC();
+        for (int p = lane; p < n; p += 64) a[p] = obuf[p];
+        WAVE_SYNC();
+        return;
     }
     // final insertion sort: lane l takes the segments that start in the 32-position words l, l+64, ...
     for (int w0 = lane; w0 * 32 < n; w0 += 64) {
@@ -605,35 +632,82 @@ struct ElimLds {
     int32_t b_slot[ECAP], b_nbr[ECAP], b_twin[ECAP], b_pos[ECAP], b_dup[ECAP];
     int32_t ksel[ECAP], t_key[ECAP], t_mv[ECAP], t_of[ECAP], t_cnt[ECAP], t_chunk[ECAP], t_list[ECAP], t_rank[ECAP], pslot[ECAP];
     WaveSortScratchT<ECAP> ws;
+    alignas(16) double skey[ECAP + 8];   // sort keys, contiguous (rank sort reads them 8 at a time)
+    SRec rec2[ECAP];                     // out-of-place buffer of the sort's final phase
 };
 
 // Rank sort == any stable sort. Exact w.r.t. std::sort when cnt <= 16 (pure
 // insertion sort, stable) or when all keys are distinct (unique answer).
 // Returns true if it wrote rec[rank] = {key, idx}; false if ties need the
 // sequential emulation.
-template <bool GREATER, class KeyF>
-__device__ __forceinline__ bool wave_rank_sort(ElimLds& L, int cnt, KeyF keyf, int lane) {
+template <bool GREATER>
+__device__ __forceinline__ bool wave_rank_sort(ElimLds& L, int cnt, int lane) {   // keys staged in L.skey[0..cnt)
+    // only this wave is running (the others wait at a barrier): LDS latency is exposed, so the keys are read
+    // eight at a time before they are compared.  NaN padding compares false with everything.
+    const int cpad = (cnt + 7) & ~7;
+    for (int q = cnt + lane; q < cpad; q += 64) L.skey[q] = __builtin_nan("");
+    WAVE_SYNC();
     bool dup = false;
     for (int i = lane; i < cnt; i += 64) {
-        double ki = keyf(i);
-        int rank = 0;
-        for (int j = 0; j < cnt; ++j) {
-            double kj = keyf(j);
-            bool before = GREATER ? (kj > ki) : (kj < ki);
-            bool eq = (kj == ki);
-            rank += (before || (eq && j < i)) ? 1 : 0;
-            dup |= (eq && j != i);
+        const double ki = L.skey[i];
+        int rank = 0, eqc = 0;
+        for (int j = 0; j < cpad; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = L.skey[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool before = GREATER ? (v[u] > ki) : (v[u] < ki);
+                const bool eq = (v[u] == ki);
+                rank += (before || (eq && (j + u) < i)) ? 1 : 0;
+                eqc += eq ? 1 : 0;
+            }
         }
+        dup |= eqc > 1;
         L.t_rank[i] = rank;
     }
     bool anydup = __ballot(dup) != 0ull;
     if (cnt > 16 && anydup) return false;
     for (int i = lane; i < cnt; i += 64) {
         int r = L.t_rank[i];
-        L.rec[r].key = keyf(i);
+        L.rec[r].key = L.skey[i];
         L.rec[r].idx = i;
     }
     return true;
+}
+
+// std::sort order of the staged keys L.skey[0..cnt) into L.rec[] = {key, source index}: one element per lane
+// up to 64 keys, stable rank when that is exact, the wave-parallel introsort restatement otherwise.
+template <bool GREATER>
+__device__ __forceinline__ void wave_sort_staged(ElimLds& L, int cnt, int lane) {
+    if (cnt <= 64) {
+        double key = lane < cnt ? L.skey[lane] : 0.0;
+        int idx = lane, pos = lane;
+        const bool ok = wave_sort64<GREATER>(key, idx, cnt, lane, L.pslot, &pos);   // pslot is free until the slots are handed out
+        if (ok) {
+            if (lane < cnt) { L.rec[pos].key = key; L.rec[pos].idx = idx; }
+            WAVE_SYNC();
+            return;
+        }
+    } else {
+        // a stable rank is only exact without ties: probe a few neighbours first (unit weights tie at once)
+        bool tie = false;
+        for (int i = lane; i < cnt; i += 64) {
+            const double ki = L.skey[i];
+            tie |= (i + 1 < cnt && L.skey[i + 1] == ki) || (i + 2 < cnt && L.skey[i + 2] == ki) || (i + 5 < cnt && L.skey[i + 5] == ki);
+        }
+        if (__ballot(tie) == 0ull && wave_rank_sort<GREATER>(L, cnt, lane)) {
+            WAVE_SYNC();
+            return;
+        }
+    }
+    WAVE_SYNC();
+    const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
+    for (int i = lane; i < cnt; i += 64) { L.rec[i].key = L.skey[i]; L.rec[i].idx = i; }
+    WAVE_SYNC();
+    if (GREATER) wave_std_sort<SRec>(L.rec, cnt, SRecGreaterKey(), WP, lane, L.rec2);
+    else wave_std_sort<SRec>(L.rec, cnt, SRecLessKey(), WP, lane, L.rec2);
+    WAVE_SYNC();
 }
 
 __device__ __forceinline__ int32_t alloc_in_column(const Arrays& A, int32_t& a, int32_t& chunk, int32_t* status) {
@@ -655,8 +729,10 @@ __device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_ato
 
 // Single-vertex path, executed by ONE wave (columns up to ECAP entries, multi-edges, any key range).
 __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
-                               int32_t acnt, int32_t abase) {
+                               int32_t acnt, int32_t abase, long long* wprof) {
     const int lane = lane_id();
+    long long wt_prev = wprof ? wall_clock64() : 0;
+#define WSTAMP(k) do { if (wprof && lane == 0) { long long _t = wall_clock64(); wprof[k] += _t - wt_prev; wt_prev = _t; } } while (0)
     const bool use_pq = A.o_v != OV_RANDOM;
     const bool coarsen = A.o_v == OV_COARSEN;
     const uint64_t lt = lanemask_lt(lane);
@@ -696,20 +772,14 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
         }
     }
     WAVE_SYNC();
+    WSTAMP(0);
 
     // ---- sort by neighbour id (std::sort semantics, :275-276) ----
-    {
-        bool done = wave_rank_sort<false>(L, len0, [&](int i) { return (double)L.a_nbr[i]; }, lane);
-        WAVE_SYNC();
-        if (!done) {
-            const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
-            for (int i = lane; i < len0; i += 64) { L.rec[i].key = (double)L.a_nbr[i]; L.rec[i].idx = i; }
-            WAVE_SYNC();
-            wave_std_sort<SRec>(L.rec, len0, SRecLessKey(), WP, lane);
-            WAVE_SYNC();
-        }
-    }
+    for (int i = lane; i < len0; i += 64) L.skey[i] = (double)L.a_nbr[i];
+    WAVE_SYNC();
+    wave_sort_staged<false>(L, len0, lane);
 
+    WSTAMP(1);
     // ---- merge multi-edges (:278-293) ----
     int m = 0;
     if (len0 <= 64) {
@@ -733,27 +803,30 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             A.e_val[L.a_twin[src]] = 0;  // duplicate's twin dies (:289)
         }
     } else {
-        if (lane == 0) {
-            int mm = 0;
-            for (int i = 0; i < len0; ++i) {
-                int s = L.rec[i].idx;
-                if (mm == 0 || L.a_nbr[s] != L.b_nbr[mm - 1]) {
-                    L.b_slot[mm] = L.a_slot[s]; L.b_nbr[mm] = L.a_nbr[s]; L.b_twin[mm] = L.a_twin[s]; L.b_val[mm] = L.a_val[s];
-                    L.b_pos[mm] = i; L.b_dup[mm] = 0;
-                    ++mm;
-                } else {
-                    L.b_val[mm - 1] += L.a_val[s];
-                    L.b_dup[mm - 1] += 1;
-                    A.e_val[L.a_twin[s]] = 0;
-                }
+        for (int p0 = 0; p0 < len0; p0 += 64) {
+            const int p = p0 + lane;
+            const bool act = p < len0;
+            const int src = act ? L.rec[p].idx : 0;
+            const int32_t nb = act ? L.a_nbr[src] : -1;
+            const int32_t nbprev = (act && p > 0) ? L.a_nbr[L.rec[p - 1].idx] : -2;
+            const bool head = act && nb != nbprev;
+            const uint64_t mask = __ballot(head);
+            const int x = m + popc64(mask & lt);
+            if (head) {
+                double val = L.a_val[src];
+                int d = 0;
+                for (int q = p + 1; q < len0 && L.a_nbr[L.rec[q].idx] == nb; ++q) { val += L.a_val[L.rec[q].idx]; ++d; }
+                L.b_slot[x] = L.a_slot[src]; L.b_nbr[x] = nb; L.b_twin[x] = L.a_twin[src]; L.b_val[x] = val;
+                L.b_pos[x] = p; L.b_dup[x] = d;
+            } else if (act) {
+                A.e_val[L.a_twin[src]] = 0;  // duplicate's twin dies (:289)
             }
-            L.t_rank[0] = mm;
+            m += popc64(mask);
         }
-        WAVE_SYNC();
-        m = L.t_rank[0];
     }
     WAVE_SYNC();
 
+    WSTAMP(2);
     // ---- neighbour metadata (PQ key, append cursor): issued now, used after ordering ----
     for (int x = lane; x < m; x += 64) {
         int32_t nb = L.b_nbr[x];
@@ -764,36 +837,16 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 
     // ---- order neighbours by o_n (:295-307) ----
     {
-        const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
-        bool done;
         if (A.o_n == ON_RANDOM || coarsen) {
             uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
-            done = wave_rank_sort<false>(L, m, [&](int i) { return keyed_order_dkey(kb, L.b_nbr[i]); }, lane);
+            for (int i = lane; i < m; i += 64) L.skey[i] = keyed_order_dkey(kb, L.b_nbr[i]);
             WAVE_SYNC();
-            if (!done) {
-                for (int i = lane; i < m; i += 64) { L.rec[i].key = keyed_order_dkey(kb, L.b_nbr[i]); L.rec[i].idx = i; }
-                WAVE_SYNC();
-                wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
-                WAVE_SYNC();
-            }
-        } else if (A.o_n == ON_ASC) {
-            done = wave_rank_sort<false>(L, m, [&](int i) { return L.b_val[i]; }, lane);
-            WAVE_SYNC();
-            if (!done) {
-                for (int i = lane; i < m; i += 64) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
-                WAVE_SYNC();
-                wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
-                WAVE_SYNC();
-            }
+            wave_sort_staged<false>(L, m, lane);
         } else {
-            done = wave_rank_sort<true>(L, m, [&](int i) { return L.b_val[i]; }, lane);
+            for (int i = lane; i < m; i += 64) L.skey[i] = L.b_val[i];
             WAVE_SYNC();
-            if (!done) {
-                for (int i = lane; i < m; i += 64) { L.rec[i].key = L.b_val[i]; L.rec[i].idx = i; }
-                WAVE_SYNC();
-                wave_std_sort<SRec>(L.rec, m, SRecGreaterKey(), WP, lane);
-                WAVE_SYNC();
-            }
+            if (A.o_n == ON_ASC) wave_sort_staged<false>(L, m, lane);
+            else wave_sort_staged<true>(L, m, lane);
         }
         for (int j = lane; j < m; j += 64) {
             int x = L.rec[j].idx;
@@ -803,6 +856,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     }
     WAVE_SYNC();
 
+    WSTAMP(3);
     double* cum = reinterpret_cast<double*>(L.rec);
     double* newv = cum + ECAP;
     int32_t status = 0;
@@ -811,21 +865,38 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 
     // ---- cumulative weights + the f / colScale / wdeg recurrences (:366-417) ----
     if (lane == 0) {
+        // the two recurrences are the result's operation order: one lane, values fetched eight at a time
+        // (nothing else runs on the CU now, so every LDS round trip would be waited for)
         double csum = 0;
-        for (int j = 0; j < m; ++j) { csum += L.a_val[j]; cum[j] = csum; }
+        for (int j0 = 0; j0 < m; j0 += 8) {
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < ECAP ? j0 + u : ECAP - 1];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { if (j0 + u < m) { csum += vv[u]; cum[j0 + u] = csum; } }
+        }
         if (!coarsen) {
             double wdeg = csum, colScale = 1;
-            for (int j = 0; j < m - 1; ++j) {
-                double w = L.a_val[j] * colScale;
-                double f = w / wdeg;
-                double omf = 1 - f;
-                newv[j] = f * omf * wdeg;
-                colScale = colScale * omf;
-                wdeg = wdeg * omf * omf;
+            for (int j0 = 0; j0 < m - 1; j0 += 8) {
+                double vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < ECAP ? j0 + u : ECAP - 1];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (j0 + u < m - 1) {
+                        double w = vv[u] * colScale;
+                        double f = w / wdeg;
+                        double omf = 1 - f;
+                        newv[j0 + u] = f * omf * wdeg;
+                        colScale = colScale * omf;
+                        wdeg = wdeg * omf * omf;
+                    }
+                }
             }
         }
     }
     WAVE_SYNC();
+    WSTAMP(4);
     const double csum = m > 0 ? cum[m - 1] : 0.0;
     const int64_t draws0 = G.n_draws;
     int ndraw = coarsen ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
@@ -849,8 +920,41 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     }
     WAVE_SYNC();
 
+    WSTAMP(5);
     // ---- per-neighbour: PQ op replay (:291,:399,:427 | :882,:896) + slots for the pushes into its column ----
     const int xk_c = (coarsen && m >= 1) ? L.t_of[koff_c] : -1;
+    if (!use_pq) {
+        // no PQ to replay (o_v = random): hand out the slots 64 positions at a time, in position order.  Lanes
+        // that drew the same target form a group; its first lane advances the target's append cursor (kept in
+        // LDS between the chunks) once per member, in lane order.
+        for (int x = lane; x < m; x += 64) L.t_list[x] = L.t_cnt[x];   // cursor before this vertex
+        WAVE_SYNC();
+        for (int j0 = 0; j0 < m - 1; j0 += 64) {
+            const int j = j0 + lane;
+            const bool act = j < m - 1;
+            const int x = act ? L.t_of[L.ksel[j]] : (-1 - lane);
+            uint64_t mymask = 0ull, rem = __ballot(act);
+            while (rem) {
+                const int l = __builtin_ctzll(rem);
+                const int xx = __shfl(x, l);
+                const uint64_t same = __ballot(act && x == xx);
+                if (act && x == xx) mymask = same;
+                rem &= ~same;
+            }
+            if (act && lane == __builtin_ctzll(mymask)) {
+                int32_t a = L.t_cnt[x], chunk = L.t_chunk[x];
+                uint64_t mm = mymask;
+                while (mm) { const int l = __builtin_ctzll(mm); mm &= mm - 1; L.t_rank[l] = alloc_in_column(A, a, chunk, &status); }
+                L.t_cnt[x] = a; L.t_chunk[x] = chunk;
+            }
+            WAVE_SYNC();
+            if (act) L.pslot[j] = L.t_rank[lane];
+            WAVE_SYNC();
+        }
+        for (int x = lane; x < m; x += 64) {
+            if (L.t_cnt[x] != L.t_list[x]) { A.app_cnt[L.b_nbr[x]] = L.t_cnt[x]; A.app_chunk[L.b_nbr[x]] = L.t_chunk[x]; }
+        }
+    } else
     for (int x = lane; x < m; x += 64) {
         int key = L.t_key[x], mv = -1;
         int32_t a = L.t_cnt[x], chunk = L.t_chunk[x];
@@ -888,6 +992,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     if (__ballot(status != 0) != 0ull) { if (lane == 0) G.status = ST_POOL_OVERFLOW; WAVE_SYNC(); return; }
     WAVE_SYNC();
 
+    WSTAMP(6);
     // ---- rewire: twin rewritten in place, new entry appended to column k (:404-414) ----
     if (coarsen) {
         for (int j = lane; j < m; j += 64) {
@@ -909,6 +1014,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
         if (lane == 0 && m >= 1) A.e_val[L.a_twin[m - 1]] = 0;  // :429-430
     }
 
+    WSTAMP(7);
     // ---- PQ commit: moved neighbours re-enter their bucket at the head, in op order ----
     if (use_pq) {
         for (int x = lane; x < m; x += 64) {
@@ -939,6 +1045,8 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     }
     if (lane == 0) G.n_draws = draws0 + ndraw;
     WAVE_SYNC();
+    WSTAMP(8);
+#undef WSTAMP
 }
 
 
@@ -1272,10 +1380,10 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
     int64_t done = 0;
     int32_t rounds = 0, singles = 0;
     long long t_prev = 0;
-    __shared__ long long s_prof[24];   // diagnostic build only (S.prof != nullptr)
+    __shared__ long long s_prof[40];   // diagnostic build only (S.prof != nullptr)
 #define PHASE_STAMP(k) do { if (S.prof && tid == 0 && g == 0) { long long _t = wall_clock64(); s_prof[k] += _t - t_prev; t_prev = _t; } } while (0)
     long long clk0 = 0, wall0 = 0;
-    if (S.prof && tid == 0 && g == 0) { for (int q = 0; q < 24; ++q) s_prof[q] = 0; t_prev = wall_clock64(); clk0 = clock64(); wall0 = t_prev; }
+    if (S.prof && tid == 0 && g == 0) { for (int q = 0; q < 40; ++q) s_prof[q] = 0; t_prev = wall_clock64(); clk0 = clock64(); wall0 = t_prev; }
 
     while (done < nelim) {
         // per-round opaque copy of the thread id: keeps the compiler from hoisting the (cheap) per-pass index
@@ -1845,7 +1953,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     }
                     if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
                 } else {
-                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase);
+                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr);
                 }
             }
             __syncthreads();
@@ -2144,7 +2252,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
         G.n_elim = (int32_t)nelim;
         if (s_status) G.status = s_status;
         G.pad0 = rounds; G.pad1 = singles;
-        if (S.prof && g == 0) { for (int q = 0; q < 20; ++q) S.prof[q] = s_prof[q]; S.prof[20] = clock64() - clk0; S.prof[21] = wall_clock64() - wall0; S.prof[22] = rounds; S.prof[23] = singles; }
+        if (S.prof && g == 0) { for (int q = 0; q < 20; ++q) S.prof[q] = s_prof[q]; S.prof[20] = clock64() - clk0; S.prof[21] = wall_clock64() - wall0; S.prof[22] = rounds; S.prof[23] = singles; for (int q = 24; q < 40; ++q) S.prof[q] = s_prof[q]; }
         gd[g] = G;
     }
 }
