@@ -2396,10 +2396,22 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
                                                    const int32_t* __restrict__ workcount) {
     __shared__ ScLdsT<CAP> L;
     __shared__ WaveSortScratchT<CAP> WS;
+    __shared__ int32_t s_tmp64[CAP == 64 ? 144 : 1];
     const WaveSortPtrs WP = {WS.ulist, WS.dlist, WS.segmark, WS.stk};
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     (void)S;
+    // columns of at most 64 entries: std::sort's permutation with one element per lane (registers + shuffles);
+    // leaves L.rec[position] = {key, source index} like the LDS paths.  False: depth limit hit, use those.
+    auto sort64 = [&](const double keyv, const int cnt, const bool greater) -> bool {
+        if (CAP != 64) return false;
+        double key = keyv;
+        int idx = lane, pos = lane;
+        const bool ok = greater ? wave_sort64<true>(key, idx, cnt, lane, s_tmp64, &pos) : wave_sort64<false>(key, idx, cnt, lane, s_tmp64, &pos);
+        if (ok && lane < cnt) { L.rec[pos].key = key; L.rec[pos].idx = idx; }
+        __syncthreads();
+        return ok;
+    };
     const int32_t nwork = *workcount;
     for (int32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const int32_t i = worklist[wi];   // lists are filled with atomics: heavy columns end up spread over the grid
@@ -2460,7 +2472,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             }
         }
         __syncthreads();
-        {
+        if (!sort64(lane < len0 ? (double)L.a_nbr[lane] : 0.0, len0, false)) {
             bool done = sc_rank_sort<false>(L, len0, [&](int q) { return (double)L.a_nbr[q]; }, lane);
             __syncthreads();
             if (!done) {
@@ -2496,6 +2508,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             bool done;
             if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
                 uint64_t kb = keyed_order_base(A.shuffle_seed, v, 1);
+                if (sort64(lane < m ? keyed_order_dkey(kb, L.b_nbr[lane]) : 0.0, m, false)) done = true; else
                 done = sc_rank_sort<false>(L, m, [&](int q) { return keyed_order_dkey(kb, L.b_nbr[q]); }, lane);
                 __syncthreads();
                 if (!done) {
@@ -2505,6 +2518,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
                     __syncthreads();
                 }
             } else if (A.o_n == ON_ASC) {
+                if (sort64(lane < m ? L.b_val[lane] : 0.0, m, false)) done = true; else
                 done = sc_rank_sort<false>(L, m, [&](int q) { return L.b_val[q]; }, lane);
                 __syncthreads();
                 if (!done) {
@@ -2514,6 +2528,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
                     __syncthreads();
                 }
             } else {
+                if (sort64(lane < m ? L.b_val[lane] : 0.0, m, true)) done = true; else
                 done = sc_rank_sort<true>(L, m, [&](int q) { return L.b_val[q]; }, lane);
                 __syncthreads();
                 if (!done) {
