@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--m", type=int, default=10)
     ap.add_argument("--o_v", default="degree")
     ap.add_argument("--o_n", default="asc")
+    ap.add_argument("--weighted", action="store_true", help="SURVEY 8(d) variant: w ~ U(0.5,1.5) per undirected edge, seed 3 (tie-free path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
@@ -47,6 +48,14 @@ def main():
     t = n // 2
     ei_cpu = graphs.barabasi_albert(n, m, 2 + rank)   # seed 2 = SURVEY 8(d) config C3
     ei = ei_cpu.to(dev)
+    w_cpu = None
+    if args.weighted:
+        import numpy as np
+        r_, c_ = ei_cpu.numpy()
+        und = np.minimum(r_, c_) * n + np.maximum(r_, c_)
+        uq, inv = np.unique(und, return_inverse=True)
+        w_cpu = torch.from_numpy(np.random.RandomState(3 + rank).uniform(0.5, 1.5, uq.shape[0])[inv])
+    w_dev = None if w_cpu is None else w_cpu.to(dev)
     perm = None
     if args.o_v == "random":
         g = torch.Generator(); g.manual_seed(1234 + rank)
@@ -54,7 +63,7 @@ def main():
     ops.set_timing(True, dev)
 
     def step():
-        sc = ops.approximate_cholesky(ei, None, n, t, args.o_v, args.o_n, perm=perm, seed=7, return_device="same")
+        sc = ops.approximate_cholesky(ei, w_dev, n, t, args.o_v, args.o_n, perm=perm, seed=7, return_device="same")
         if world > 1 and not args.no_gather:
             from rlap_amd.distributed import all_gather_rows
             sc, _ = all_gather_rows(sc)
@@ -100,7 +109,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         except OSError:
             pass
-        default_cfg = (n == 1_000_000 and m == 10 and args.o_v == "degree" and args.o_n == "asc")
+        default_cfg = (n == 1_000_000 and m == 10 and args.o_v == "degree" and args.o_n == "asc" and not args.weighted)
         def roof(name, b, ms):
             a = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             tr = pmc.get(name) if default_cfg else None
@@ -111,7 +120,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BA(N={n}, m={m}) nnz={st['nnz']}, num_remove={t}, o_v={args.o_v}, o_n={args.o_n}, "
-                                   "unit weights; one graph per GPU" + ("" if world == 1 or args.no_gather else " + RCCL all-gather of sc_edge_info")},
+                                   + ("weights U(0.5,1.5)" if args.weighted else "unit weights") + "; one graph per GPU" + ("" if world == 1 or args.no_gather else " + RCCL all-gather of sc_edge_info")},
             "output_edges_per_s": world * mrows * args.steps / elapsed,
             "out_rows": mrows, "n_eliminated": n_elim, "n_draws": D,
             "phase_ms": {k: avg(k) for k in ("ms_setup", "ms_elim", "ms_output", "ms_sc_merge", "ms_sc_compact", "ms_total")},
@@ -124,7 +133,7 @@ def main():
             import numpy as np
             import oracle  # cpu_baseline leg only
             t1 = time.perf_counter()
-            ref, ost = oracle.approximate_cholesky(ei_cpu.numpy(), None, n, t, args.o_v, args.o_n,
+            ref, ost = oracle.approximate_cholesky(ei_cpu.numpy(), None if w_cpu is None else w_cpu.numpy(), n, t, args.o_v, args.o_n,
                                                    perm=None if perm is None else perm.numpy(), shuffle_seed=7, return_stats=True)
             cpu_s = time.perf_counter() - t1
             got = sc.cpu().numpy()

@@ -58,7 +58,7 @@ struct rlap_handle_s {
     int64_t rng_len = 0;
     DevBuf scr_rec, scr_i32, scr_f64;
     // output
-    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, counters, biglist, biglists;
+    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, counters, biglist, biglists, hugelists;
     // growth factors kept across calls
     double pool_factor = 1.0;
     double log_factor = 2.0;
@@ -340,8 +340,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = bigcap; SS.top = counters + 0;
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
     if (S > 0) {
-        ENSURE(h->biglist, 4 * 4 * (S + 1));
-        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 4 ints: tiers 0..3
+        ENSURE(h->biglist, 4 * 5 * (S + 1));
+        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 5 ints: tiers 0..4
         launch_sc_merge(s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
                         h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1, h->biglist.as<int32_t>(), tiercounts);
         HIPCHK(hipGetLastError());
@@ -359,6 +359,13 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s, A, order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
                            biglist_ptr, bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1,
                            h->biglists.as<uint16_t>());
+        HIPCHK(hipGetLastError());
+        // longer than the LDS record array (hubs of weighted graphs): records in global scratch, a few workgroups
+        constexpr unsigned NHUGE = 32;
+        ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
+        hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s, A, order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
+                           h->biglist.as<int32_t>() + 4 * (size_t)S, reinterpret_cast<int32_t*>(counters + 4) + 4, h->tmp_nbr.as<int32_t>(),
+                           h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1, h->hugelists.as<uint16_t>(), SS.rec, SS.top);
         HIPCHK(hipGetLastError());
     }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[4], s));
@@ -423,7 +430,7 @@ int rlap_destroy(rlap_handle h) {
                       &h->deg, &h->colptr, &h->slot_col, &h->gcol, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
                       &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->tcount, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
-                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters, &h->biglist, &h->biglists};
+                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters, &h->biglist, &h->biglists, &h->hugelists};
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     delete h;

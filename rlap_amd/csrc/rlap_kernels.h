@@ -11,6 +11,7 @@ enum { FLAG_RANGE = 0, FLAG_CROSS = 1, FLAG_COUNT = 4 };
 constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
 constexpr int SCAP = 512;  // output pass: same
 constexpr int BIGCAP = 8192;  // output pass, long columns: one workgroup with a 128 KB LDS record array
+constexpr int HUGECAP = 65535; // output pass, longer still: records in global scratch (uint16 stop lists)
 
 // Global scratch for columns too long for LDS (sequential fallback).
 struct ElimScratch {
@@ -77,6 +78,9 @@ __global__ void k_debug_wave_sort(const double* keys, const int32_t* offs, int32
 __global__ void k_sc_biglist(const int32_t* ext, int32_t S, int32_t keyed, int32_t* list, int32_t* count);
 __global__ void k_sc_merge_big(Arrays A, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
                                int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists);
+__global__ void k_sc_merge_huge(Arrays A, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
+                                int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists, SRec* scratch,
+                                unsigned long long* scratch_top);
 __global__ void k_sc_compact(const uint32_t* order, const int32_t* cnt, const int64_t* row_off, const int64_t* tmp_off,
                              const int32_t* tmp_nbr, const double* tmp_val, int32_t S, double* out);
 __global__ void k_graph_rows(const int64_t* surv_base, const int64_t* row_off, int32_t G, int64_t* out_ptr);

@@ -253,7 +253,9 @@ typedef WaveSortScratchT<SCAP> WaveSortScratch;
 
 struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; };
 
-template <class T, class Less>
+// REGT > 0: arrays of at most 64*REGT elements run the final phase with one lane per ELEMENT, the elements held
+// in registers between the rank computation and the stores (no second buffer).
+template <class T, class Less, int REGT = 0>
 __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane, T* obuf = nullptr) {
     struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
     if (n < 2) return;
@@ -361,6 +363,39 @@ __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int
         if (lane == 0) atomicOr(&W.segmark[first >> 5], 1u << (first & 31));
         (void)heap_sorted;
         WAVE_SYNC();
+    }
+    if (REGT > 0 && n <= 64 * REGT) {
+        T vv[REGT > 0 ? REGT : 1];
+        int rr[REGT > 0 ? REGT : 1];
+#pragma unroll
+        for (int t = 0; t < REGT; ++t) {
+            const int p = lane + 64 * t;
+            rr[t] = -1;
+            if (p < n) {
+                const int w = p >> 5;
+                const uint32_t here = W.segmark[w];
+                const uint32_t lowm = here & (0xFFFFFFFFu >> (31 - (p & 31)));
+                int s0;
+                if (lowm) s0 = w * 32 + 31 - __builtin_clz(lowm);
+                else { int w1 = w - 1; uint32_t bb = W.segmark[w1]; while (bb == 0u) { --w1; bb = W.segmark[w1]; } s0 = w1 * 32 + 31 - __builtin_clz(bb); }
+                const uint32_t highm = ((p & 31) == 31) ? 0u : (here & (0xFFFFFFFFu << ((p & 31) + 1)));
+                int e0 = n;
+                if (highm) e0 = w * 32 + __builtin_ctz(highm);
+                else { for (int w1 = w + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } } }
+                const T v = a[p];
+                int r = s0;
+                for (int q = s0; q < e0; ++q) {
+                    const T x = a[q];
+                    r += (q != p && (less(x, v) || (!less(v, x) && q < p))) ? 1 : 0;
+                }
+                vv[t] = v; rr[t] = r;
+            }
+        }
+        WAVE_SYNC();
+#pragma unroll
+        for (int t = 0; t < REGT; ++t) if (rr[t] >= 0) a[rr[t]] = vv[t];
+        WAVE_SYNC();
+        return;
     }
     if (obuf) {
         // final insertion sort == stable sort of every marked segment (<= 16 elements): one lane per ELEMENT
@@ -633,7 +668,6 @@ struct ElimLds {
     int32_t ksel[ECAP], t_key[ECAP], t_mv[ECAP], t_of[ECAP], t_cnt[ECAP], t_chunk[ECAP], t_list[ECAP], t_rank[ECAP], pslot[ECAP];
     WaveSortScratchT<ECAP> ws;
     alignas(16) double skey[ECAP + 8];   // sort keys, contiguous (rank sort reads them 8 at a time)
-    SRec rec2[ECAP];                     // out-of-place buffer of the sort's final phase
 };
 
 // Rank sort == any stable sort. Exact w.r.t. std::sort when cnt <= 16 (pure
@@ -705,8 +739,8 @@ __device__ __forceinline__ void wave_sort_staged(ElimLds& L, int cnt, int lane) 
     const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
     for (int i = lane; i < cnt; i += 64) { L.rec[i].key = L.skey[i]; L.rec[i].idx = i; }
     WAVE_SYNC();
-    if (GREATER) wave_std_sort<SRec>(L.rec, cnt, SRecGreaterKey(), WP, lane, L.rec2);
-    else wave_std_sort<SRec>(L.rec, cnt, SRecLessKey(), WP, lane, L.rec2);
+    if (GREATER) wave_std_sort<SRec, SRecGreaterKey, ECAP / 64>(L.rec, cnt, SRecGreaterKey(), WP, lane);
+    else wave_std_sort<SRec, SRecLessKey, ECAP / 64>(L.rec, cnt, SRecLessKey(), WP, lane);
     WAVE_SYNC();
 }
 
@@ -2422,7 +2456,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             // long column: k_sc_merge_big takes it (LDS), unless it is too long for that or the order is keyed:
             // then the sequential form in global scratch (one lane)
             const bool keyed_order = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
-            if (lane == 0 && (keyed_order || ex > BIGCAP)) {
+            if (lane == 0 && (keyed_order || ex > HUGECAP)) {
                 unsigned long long off = atomicAdd(SS.top, (unsigned long long)ex);
                 ColBuf B = SS.colbuf((int64_t)off);
                 GraphDesc D = gd[vgraph[v]];
@@ -2472,13 +2506,15 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             }
         }
         __syncthreads();
+        constexpr int RT = (CAP + 63) / 64;
+        constexpr bool RANK_FIRST = CAP <= 64;   // longer columns: the stable rank is O(n^2/64), the restatement O(n log n / 64)
         if (!sort64(lane < len0 ? (double)L.a_nbr[lane] : 0.0, len0, false)) {
-            bool done = sc_rank_sort<false>(L, len0, [&](int q) { return (double)L.a_nbr[q]; }, lane);
+            bool done = RANK_FIRST ? sc_rank_sort<false>(L, len0, [&](int q) { return (double)L.a_nbr[q]; }, lane) : false;
             __syncthreads();
             if (!done) {
                 for (int q = lane; q < len0; q += 64) { L.rec[q].key = (double)L.a_nbr[q]; L.rec[q].idx = q; }
                 __syncthreads();
-                wave_std_sort<SRec>(L.rec, len0, SRecLessKey(), WP, lane);
+                wave_std_sort<SRec, SRecLessKey, RT>(L.rec, len0, SRecLessKey(), WP, lane);
                 __syncthreads();
             }
         }
@@ -2509,32 +2545,32 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
                 uint64_t kb = keyed_order_base(A.shuffle_seed, v, 1);
                 if (sort64(lane < m ? keyed_order_dkey(kb, L.b_nbr[lane]) : 0.0, m, false)) done = true; else
-                done = sc_rank_sort<false>(L, m, [&](int q) { return keyed_order_dkey(kb, L.b_nbr[q]); }, lane);
+                done = RANK_FIRST ? sc_rank_sort<false>(L, m, [&](int q) { return keyed_order_dkey(kb, L.b_nbr[q]); }, lane) : false;
                 __syncthreads();
                 if (!done) {
                     for (int q = lane; q < m; q += 64) { L.rec[q].key = keyed_order_dkey(kb, L.b_nbr[q]); L.rec[q].idx = q; }
                     __syncthreads();
-                    wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
+                    wave_std_sort<SRec, SRecLessKey, RT>(L.rec, m, SRecLessKey(), WP, lane);
                     __syncthreads();
                 }
             } else if (A.o_n == ON_ASC) {
                 if (sort64(lane < m ? L.b_val[lane] : 0.0, m, false)) done = true; else
-                done = sc_rank_sort<false>(L, m, [&](int q) { return L.b_val[q]; }, lane);
+                done = RANK_FIRST ? sc_rank_sort<false>(L, m, [&](int q) { return L.b_val[q]; }, lane) : false;
                 __syncthreads();
                 if (!done) {
                     for (int q = lane; q < m; q += 64) { L.rec[q].key = L.b_val[q]; L.rec[q].idx = q; }
                     __syncthreads();
-                    wave_std_sort<SRec>(L.rec, m, SRecLessKey(), WP, lane);
+                    wave_std_sort<SRec, SRecLessKey, RT>(L.rec, m, SRecLessKey(), WP, lane);
                     __syncthreads();
                 }
             } else {
                 if (sort64(lane < m ? L.b_val[lane] : 0.0, m, true)) done = true; else
-                done = sc_rank_sort<true>(L, m, [&](int q) { return L.b_val[q]; }, lane);
+                done = RANK_FIRST ? sc_rank_sort<true>(L, m, [&](int q) { return L.b_val[q]; }, lane) : false;
                 __syncthreads();
                 if (!done) {
                     for (int q = lane; q < m; q += 64) { L.rec[q].key = L.b_val[q]; L.rec[q].idx = q; }
                     __syncthreads();
-                    wave_std_sort<SRec>(L.rec, m, SRecGreaterKey(), WP, lane);
+                    wave_std_sort<SRec, SRecGreaterKey, RT>(L.rec, m, SRecGreaterKey(), WP, lane);
                     __syncthreads();
                 }
             }
@@ -2549,19 +2585,19 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
     }
 }
 
-// work lists per capacity tier (0: <=64, 1: <=192, 2: the rest that k_sc_merge_big does not take, 3: k_sc_merge_big)
+// work lists per capacity tier (0: <=64, 1: <=192, 2: <=512 and what the long-column kernels do not take, 3: k_sc_merge_big, 4: k_sc_merge_huge)
 __global__ __launch_bounds__(256) void k_sc_tierlists(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tier = -1;
     if (i < S) {
         int32_t e = ext[i];
-        tier = e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= BIGCAP && !keyed) ? 3 : 2));
+        tier = e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && !keyed && e <= HUGECAP) ? (e <= BIGCAP ? 3 : 4) : 2));
     }
     // one atomic per wave and tier: neighbouring columns stay neighbours in the list (locality of the
     // staged rows), while the waves' chunks interleave (balance)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 5; ++t) {
         uint64_t mk = __ballot(tier == t);
         if (mk == 0ull) continue;
         int32_t base = 0;
@@ -2600,17 +2636,21 @@ __global__ void k_sc_biglist(const int32_t* __restrict__ ext, int32_t S, int32_t
     if (e > SCAP && e <= BIGCAP) list[atomicAdd(count, 1)] = i;
 }
 
-__global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
-                                                     const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
-                                                     const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
-                                                     double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
-                                                     unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists) {
-    extern __shared__ Rec2 R[];   // BIGCAP records
-    __shared__ int32_t s_m;
-    __shared__ uint32_t s_segmark[BIGCAP / 32 + 2];
+// HUGE = false: SCAP < extent <= BIGCAP, records in LDS.  HUGE = true: BIGCAP < extent <= HUGECAP (a hub of a
+// weighted graph), records in global scratch (L2), both sorts by the wave-parallel restatement.
+template <bool HUGE>
+__device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+                                                   const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
+                                                   const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
+                                                   double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
+                                                   unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists,
+                                                   Rec2* lds_R, Rec2* glob_R, unsigned long long* glob_top) {
+    constexpr int LCAP = HUGE ? HUGECAP : BIGCAP;
+    __shared__ uint32_t s_segmark[LCAP / 32 + 2];
     __shared__ int32_t s_stk[3 * 48];
+    __shared__ unsigned long long s_off;
     // stop lists of the partition emulation: global scratch, one region per workgroup
-    const WaveSortPtrs WP = {lists + (size_t)blockIdx.x * 2 * (BIGCAP + 2), lists + (size_t)blockIdx.x * 2 * (BIGCAP + 2) + (BIGCAP + 2), s_segmark, s_stk};
+    const WaveSortPtrs WP = {lists + (size_t)blockIdx.x * 2 * (LCAP + 2), lists + (size_t)blockIdx.x * 2 * (LCAP + 2) + (LCAP + 2), s_segmark, s_stk};
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     const int32_t nbig = *count;
@@ -2620,6 +2660,12 @@ __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* _
         const int64_t toff = tmp_off[i];
         const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
         const int32_t acnt = A.app_cnt[v];
+        Rec2* R = lds_R;
+        if (HUGE) {
+            if (lane == 0) s_off = atomicAdd(glob_top, (unsigned long long)ext[i]);
+            __syncthreads();
+            R = glob_R + s_off;
+        }
         int len0 = 0;
         {
             int32_t idx = acnt - 1, base = A.app_chunk[v];
@@ -2654,83 +2700,53 @@ __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* _
             }
         }
         __syncthreads();
-        // sort by id (:314-315).  Distinct ids have one sorted order, so a wave-parallel bitonic sort is
-        // exact; if a multi-edge shows up, gather again and let one lane emulate std::sort.
-        bool exact_needed = false;
-        {
-            int32_t npow = 64;
-            while (npow < len0) npow <<= 1;
-            for (int32_t q = len0 + lane; q < npow; q += 64) { R[q].a = 1e300; R[q].b = 0; }
-            __syncthreads();
-            for (int32_t k = 2; k <= npow; k <<= 1) {
-                for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                    for (int32_t t = lane; t < (npow >> 1); t += 64) {
-                        int32_t lo = ((t / jj) * (jj << 1)) + (t % jj);
-                        int32_t hi = lo + jj;
-                        bool up = ((lo & k) == 0);
-                        Rec2 x = R[lo], y = R[hi];
-                        if ((x.a > y.a) == up) { R[lo] = y; R[hi] = x; }
-                    }
-                    __syncthreads();
-                }
-            }
-            bool dup = false;
-            for (int32_t q = 1 + lane; q < len0; q += 64) dup |= (R[q].a == R[q - 1].a);
-            exact_needed = __ballot(dup) != 0ull;
-        }
-        if (exact_needed) {
-            // rare: re-gather in traversal order for the exact emulation
-            __syncthreads();
-            len0 = 0;
-            int32_t idx = acnt - 1, base = A.app_chunk[v];
-            int c = idx >= 0 ? chunk_of(idx) : 0;
-            while (idx >= 0) {
-                int32_t cs = chunk_start(c);
-                for (int32_t t0 = idx; t0 >= cs; t0 -= 64) {
-                    int32_t t = t0 - lane;
-                    bool valid = t >= cs;
-                    int32_t s = base + 1 + (t - cs);
-                    double val = 0; int32_t nb = 0;
-                    if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
-                    bool live = valid && val > 0;
-                    uint64_t mask = __ballot(live);
-                    int pos = len0 + popc64(mask & lt);
-                    if (live) { R[pos].a = (double)nb; R[pos].b = val; }
-                    len0 += popc64(mask);
-                }
-                int32_t prev = A.e_nbr[base];
-                idx = cs - 1; base = prev; --c;
-            }
-            for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
-                int32_t s = s0 - lane;
-                bool valid = s >= cp0;
-                double val = 0; int32_t nb = 0;
-                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
-                bool live = valid && val > 0;
-                uint64_t mask = __ballot(live);
-                int pos = len0 + popc64(mask & lt);
-                if (live) { R[pos].a = (double)nb; R[pos].b = val; }
-                len0 += popc64(mask);
-            }
-            __syncthreads();
-        }
-        if (exact_needed) { wave_std_sort<Rec2>(R, len0, Rec2LessA(), WP, lane); __syncthreads(); }
-        if (lane == 0) {
-            int32_t m = 0;
-            for (int32_t q = 0; q < len0; ++q) {               // :317-329
-                if (m == 0 || R[q].a != R[m - 1].a) { R[m] = R[q]; ++m; }
-                else R[m - 1].b += R[q].b;
-            }
-            s_m = m;
-        }
+        // sort by id (:314-315), std::sort semantics (the gather order is the traversal order)
+        wave_std_sort<Rec2>(R, len0, Rec2LessA(), WP, lane);
         __syncthreads();
-        if (A.o_n == ON_ASC) wave_std_sort<Rec2>(R, s_m, Rec2LessB(), WP, lane); else wave_std_sort<Rec2>(R, s_m, Rec2GreaterB(), WP, lane);   // :331-338
+        // merge (:317-329), 64 positions at a time: heads by ballot, sums in sorted order; all reads of a chunk
+        // (its look-ahead included) come before its writes, which land at or below the chunk
+        int m = 0;
+        for (int32_t p0 = 0; p0 < len0; p0 += 64) {
+            const int32_t p = p0 + lane;
+            const bool act = p < len0;
+            Rec2 me = {0.0, 0.0};
+            double prev = -1.0;
+            if (act) { me = R[p]; if (p > 0) prev = R[p - 1].a; }
+            const bool head = act && me.a != prev;
+            if (head) for (int32_t q = p + 1; q < len0 && R[q].a == me.a; ++q) me.b += R[q].b;
+            const uint64_t mask = __ballot(head);
+            const int32_t x = m + popc64(mask & lt);
+            __syncthreads();
+            if (head) R[x] = me;
+            __syncthreads();
+            m += popc64(mask);
+        }
+        if (A.o_n == ON_ASC) wave_std_sort<Rec2>(R, m, Rec2LessB(), WP, lane); else wave_std_sort<Rec2>(R, m, Rec2GreaterB(), WP, lane);   // :331-338
         __syncthreads();
-        const int32_t m = s_m;
         for (int32_t j = lane; j < m; j += 64) { tmp_nbr[toff + j] = (int32_t)R[j].a; tmp_val[toff + j] = R[j].b; }
         if (lane == 0) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)len0); }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+                                                     const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
+                                                     const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
+                                                     double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
+                                                     unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists) {
+    extern __shared__ Rec2 R_lds[];   // BIGCAP records
+    sc_merge_long_body<false>(A, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, R_lds, nullptr, nullptr);
+}
+
+__global__ __launch_bounds__(64) void k_sc_merge_huge(Arrays A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+                                                      const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
+                                                      const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
+                                                      double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
+                                                      unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists,
+                                                      SRec* __restrict__ scratch, unsigned long long* __restrict__ scratch_top) {
+    static_assert(sizeof(Rec2) == sizeof(SRec), "the long-column records borrow the output pass's record scratch");
+    sc_merge_long_body<true>(A, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, nullptr,
+                             reinterpret_cast<Rec2*>(scratch), scratch_top);
 }
 
 // Pass B (the prefix-sum compaction): row r of the output belongs to the surviving vertex i with

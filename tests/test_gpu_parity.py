@@ -174,6 +174,19 @@ def test_long_columns_random_order(ops, o_n):
             assert_same(b, a, f"{name} {o_n} {'unit' if w is None else 'weighted'}")
 
 
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_long_surviving_columns(ops, o_n):
+    """Output pass: surviving columns beyond the 512-entry tiers (LDS record array, up to 8192 entries) and
+    beyond that (records in global scratch), unit weights (all ties) and tie-free weights."""
+    for n in (3000, 12000):
+        ei = star(n)
+        for w in (None, sym_weights(ei, n, 2)):
+            for t in (0, 50):
+                a = oracle.approximate_cholesky(ei, w, n, t, "degree", o_n, shuffle_seed=8)
+                b = gpu_call(ops, ei, w, n, t, "degree", o_n, seed=8)
+                assert_same(b, a, f"star{n} t={t} {o_n} {'unit' if w is None else 'weighted'}")
+
+
 def test_reference_unit_test_shape(ops):
     # reference tests/test_rlap.py:39-61: BA(100, 50), ones((1,E)) weights, t=50, random/asc
     n = 100

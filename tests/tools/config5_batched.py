@@ -5,7 +5,8 @@ sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch
 from rlap_amd import graphs, ops
 import oracle
-G, n, m = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 4096, 8
+G, n, m = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1024, 4096, 8
+CPU_PROCS = int(sys.argv[sys.argv.index("--cpu-procs") + 1]) if "--cpu-procs" in sys.argv else 0
 eis = [graphs.barabasi_albert(n, m, 1000 + g) for g in range(G)]
 big, node_ptr = graphs.batch_disjoint(eis, [n] * G)
 big = big.cuda()
@@ -29,3 +30,24 @@ for o_v in ("degree", "random"):
         got = sc[int(rp[g]):int(rp[g + 1])].copy(); got[:, :2] -= g * n
         bad += not (got.shape == ref.shape and np.array_equal(got, ref))
     print("  oracle check on 16 graphs: mismatches =", bad)
+
+
+# the fair multi-core CPU comparison -- one graph per process on the host cores (oracle = CPU port)
+def _cpu_one(g):
+    import numpy as _np
+    ei = graphs.barabasi_albert(n, m, 1000 + g).numpy()
+    pm = _np.random.RandomState(g).permutation(n)
+    t0 = time.perf_counter()
+    oracle.approximate_cholesky(ei, None, n, n // 2, "random", "asc", perm=pm)
+    return time.perf_counter() - t0
+
+
+if CPU_PROCS > 0:
+    import multiprocessing as mp
+    sample = 8 * CPU_PROCS
+    with mp.get_context("fork").Pool(CPU_PROCS) as pool:
+        t0 = time.perf_counter()
+        per = pool.map(_cpu_one, range(sample))
+        wall = time.perf_counter() - t0
+    print(f"CPU port, random/asc, {CPU_PROCS} processes x 1 graph each: {sample} graphs in {wall*1e3:.0f} ms (incl. graph generation) -> "
+          f"{sample*(n//2)/wall:.3e} eliminated vertices/s; per-graph oracle call {1e3*sum(per)/len(per):.1f} ms on one core")

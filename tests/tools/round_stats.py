@@ -1,7 +1,7 @@
 """Round statistics of the batch elimination on the CPU mirror (tests/csrc/host_mirror.cc): how many rounds,
-how many vertices per round, and what ended the rounds.  usage: round_stats.py N m o_v o_n B bc"""
+how many vertices per round, and what ended the rounds.  usage: tests/tools/round_stats.py N m o_v o_n B bc"""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import conftest, test_core_mirror as tcm
