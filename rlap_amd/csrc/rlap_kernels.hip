@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     E.val = lv[k]; E.nbr = ln[k];
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave
             PHASE_STAMP(9);
             // rank of every live entry among its column's live entries by id: with distinct ids the
             // sorted order is unique, so no std::sort emulation is needed (equal ids -> single-vertex path).
@@ -1650,7 +1650,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     }
                 }
             }
-            __syncthreads();
+            WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave
             PHASE_STAMP(12);
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
@@ -1698,7 +1698,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             }
             PHASE_STAMP(15);
             PHASE_STAMP(18);
-            __syncthreads();
+            WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave
             PHASE_STAMP(16);
             // o_n order with std::sort semantics under ties.  All-equal keys (unit weights): identity for
             // m <= 16, a precomputed permutation above.  Otherwise a stable rank is exact for m <= 16
@@ -1736,7 +1736,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                 }
             }
             PHASE_STAMP(17);
-            __syncthreads();
+            WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave
             PHASE_STAMP(13);
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
@@ -1749,7 +1749,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             }
             if (BC == 64) {
                 // one wave = one candidate: std::sort's permutation with the elements in registers
-                __syncthreads();   // rank writes of ksel above vs. the sort's own
+                WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave   // rank writes of ksel above vs. the sort's own
                 int32_t* tmp = L.pslot + (tid >> 6) * 256;   // pslot is not live before the commit
 #pragma unroll 1
                 for (int k = 0; k < PASSES; ++k) {
@@ -1765,16 +1765,9 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     else if (lane == 0) { Arrays A3 = A; cand_order_index_call(A3, C); }
                     WAVE_SYNC();
                 }
-                if (tid < nc) {
-                    Cand& C = L.cand[tid];
-                    if (!(C.flags & (CF_BIG | CF_DUP | CF_READY))) {
-                        const int32_t m = C.m;
-                        C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
-                    }
-                }
             } else {
                 // half a wave = one candidate: the same with two independent sorts per wave
-                __syncthreads();   // rank writes of ksel above vs. the sort's own
+                WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave   // rank writes of ksel above vs. the sort's own
                 int32_t* tmp = L.pslot + (tid >> 6) * 256;   // pslot is not live before the commit
 #pragma unroll 1
                 for (int k = 0; k < PASSES; ++k) {
@@ -1798,15 +1791,8 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                     }
                     WAVE_SYNC();
                 }
-                if (tid < nc) {
-                    Cand& C = L.cand[tid];
-                    if (!(C.flags & (CF_BIG | CF_DUP | CF_READY))) {
-                        const int32_t m = C.m;
-                        C.ndraw = (A.o_v == OV_COARSEN) ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
-                    }
-                }
             }
-            __syncthreads();
+            WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave
             PHASE_STAMP(14);
             // apply the permutation: every position fetches its source entry, then all store
             double pv[PASSES]; int32_t pn[PASSES], pt[PASSES]; bool pa[PASSES];
@@ -1817,9 +1803,12 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                 pa[k] = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP | CF_READY)) && (j < L.cand[i].m);
                 pv[k] = 0; pn[k] = 0; pt[k] = 0;
                 if (__ballot(pa[k]) == 0ull) continue;
-                if (pa[k]) { const Ent& Sx = L.cand[i].e[L.cand[i].ksel[j]]; pv[k] = Sx.val; pn[k] = Sx.nbr; pt[k] = Sx.twin; }
+                if (pa[k]) {
+                    const Ent& Sx = L.cand[i].e[L.cand[i].ksel[j]]; pv[k] = Sx.val; pn[k] = Sx.nbr; pt[k] = Sx.twin;
+                    if (j == 0) { const int32_t m = L.cand[i].m; L.cand[i].ndraw = (A.o_v == OV_COARSEN) ? 1 : (m > 1 ? m - 1 : 0); }   // m >= 1 here
+                }
             }
-            __syncthreads();
+            WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 if (__ballot(pa[k]) == 0ull) continue;
