@@ -1088,12 +1088,12 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 // Single-vertex path for columns beyond ECAP entries, o_v = random (hubs met early in a random order;
 // no PQ to replay).  One wave; the sort records, the stop lists and afterwards the cumulative weights live
 // in the workgroup's LDS (the batch round's storage is free while a single vertex is eliminated), the column
-// itself in the graph's global scratch.  Every step is O(len/64) or the O(len log len / 64) sort; the only
+// itself in the graph's global scratch (BIGE = 7168 entries with the 1024-thread workgroup, 1536 with the 256-thread one).  Every step is O(len/64) or the O(len log len / 64) sort; the only
 // lane-serial parts are the two floating-point recurrences, whose order of operations is the result.
 // Returns false (nothing changed) when the column does not fit: the caller falls back to the sequential form.
 // ---------------------------------------------------------------------------
-constexpr int BIGE = 7168;
-struct BigElimLds {
+template <int BIGE>
+struct BigElimLdsT {
     union {
         SRec rec[BIGE];
         struct { double cum[BIGE]; double newv[BIGE]; } c;
@@ -1105,7 +1105,8 @@ struct BigElimLds {
     int32_t tmp[64];
 };
 
-__device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, BigElimLds& L, const ColBuf& B, int32_t cap, int32_t v,
+template <int BIGE>
+__device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, BigElimLdsT<BIGE>& L, const ColBuf& B, int32_t cap, int32_t v,
                                                 int32_t cp0, int32_t cp1, int32_t acnt, int32_t abase) {
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
@@ -1272,36 +1273,36 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
 // ---------------------------------------------------------------------------
 // Batch kernel
 // ---------------------------------------------------------------------------
-constexpr int NT = 1024;      // threads per workgroup of the batch kernel (measured faster than 512 despite tighter registers)
-constexpr int NWAVE = NT / 64;
-constexpr int SLOTS = 4096;   // candidates x slots per round: 128 x 32 (one half-wave per candidate) or 64 x 64 (one wave)
-constexpr int PASSES = SLOTS / NT;   // (candidate, slot) pairs per thread
-constexpr int MCAP = NT;      // PQ moves per round: one per thread, sorted in registers + LDS
-constexpr int CCAP = 512;     // contended (target, candidate) records per round
+// Two shapes of the workgroup: 1024 threads (4096 slots per round, ~156 KB LDS, one workgroup per CU) for a few large
+// graphs; 256 threads (1024 slots, ~50 KB, three workgroups per CU) when a batch holds more graphs than the device has
+// CUs -- small graphs give short rounds anyway and three of them hide each other's latency.
+constexpr int PASSES = 4;     // (candidate, slot) pairs per thread: slots per round = 4 x threads
 
 struct CRec { int32_t x, i, j; };
 
-template <int BC>
+template <int BC, int NTT>
 struct BatchLdsT {
-    CandT<BC> cand[SLOTS / BC];
-    uint64_t mkey[MCAP];
-    int32_t mval[MCAP];
-    int32_t hidx[MCAP];
-    int32_t pslot[SLOTS];   // slot of the entry position p of candidate i appends (commit phase)
-    CRec cont[CCAP];
-    CRec csorted[CCAP];
-    int32_t scan[NWAVE + 8];
+    CandT<BC> cand[4 * NTT / BC];
+    uint64_t mkey[NTT];       // PQ moves per round: one per thread, sorted in registers + LDS
+    int32_t mval[NTT];
+    int32_t hidx[NTT];
+    int32_t pslot[4 * NTT];   // slot of the entry position p of candidate i appends (commit phase)
+    CRec cont[NTT / 2];       // contended (target, candidate) records per round
+    CRec csorted[NTT / 2];
+    int32_t scan[NTT / 64 + 8];
 };
 
-template <int BC>
+template <int BC, int NTT>
 union ElimSharedT {
-    BatchLdsT<BC> b;
+    BatchLdsT<BC, NTT> b;
     ElimLds e;
-    BigElimLds g;
+    BigElimLdsT<(NTT >= 1024 ? 7168 : 1536)> g;
 };
-static_assert(sizeof(BigElimLds) <= sizeof(BatchLdsT<64>) && sizeof(BigElimLds) <= sizeof(BatchLdsT<32>), "the long-column path borrows the batch round's LDS");
+static_assert(sizeof(ElimSharedT<64, 1024>) == sizeof(BatchLdsT<64, 1024>) && sizeof(ElimSharedT<32, 1024>) == sizeof(BatchLdsT<32, 1024>),
+              "the single-vertex paths borrow the batch round's LDS");
 
-// exclusive block scan over NT threads; returns exclusive prefix, *total = sum
+// exclusive block scan over the workgroup's NWAVE waves; returns exclusive prefix, *total = sum
+template <int NWAVE>
 __device__ __noinline__ int block_excl_scan(int val, int* scratch, int* total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int incl = val;
@@ -1316,8 +1317,9 @@ __device__ __noinline__ int block_excl_scan(int val, int* scratch, int* total) {
 }
 
 // ordered block compaction helper: position of a flagged thread among flagged threads (thread order)
+template <int NWAVE>
 __device__ __forceinline__ int block_rank(bool flag, int* scratch, int* total) {
-    return block_excl_scan(flag ? 1 : 0, scratch, total);
+    return block_excl_scan<NWAVE>(flag ? 1 : 0, scratch, total);
 }
 
 
@@ -1373,21 +1375,26 @@ __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G
 
 // Specialised on (o_v, o_n): the mode tests fold away, which keeps the round loop's code (executed once
 // per round by every wave) small enough for the instruction cache.
-template <int OV, int ON, int BC>
-__global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
+template <int OV, int ON, int BC, int NTT>
+__global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
                                                            int32_t* __restrict__ batch_pos, int32_t* __restrict__ tcount) {
+    constexpr int NT = NTT;            // threads per workgroup
+    constexpr int NWAVE = NT / 64;
+    constexpr int SLOTS = PASSES * NT; // candidates x slots per round
+    constexpr int MCAP = NT;           // PQ moves per round
+    constexpr int CCAP = NT / 2;       // contended records per round
     // BC slots per candidate: a group of BC lanes (half a wave or a whole wave) works on one candidate
     constexpr int BCAP = BC;
     constexpr int BATCH = SLOTS / BC;
     typedef CandT<BC> Cand;
-    typedef BatchLdsT<BC> BatchLds;
+    typedef BatchLdsT<BC, NTT> BatchLds;
     constexpr bool MERGE = (BC == 64 && OV == OV_RANDOM);           // multi-edges merged inside the candidate (rlap_core.h::cand_merges_multi_edges)
     constexpr int GSH = 64 - BC;                                  // lane & GSH = first lane of my group
     constexpr uint64_t GMASK = BC == 64 ? ~0ull : 0xFFFFFFFFull;   // a group's part of a 64-bit ballot
     Arrays A = A_in;
     A.o_v = OV;
     A.o_n = ON;
-    __shared__ ElimSharedT<BC> sh;
+    __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status;
     __shared__ uint8_t s_eqperm[BC - 16][BC];   // std::sort's permutation of n = 17..BC all-equal keys
@@ -1396,15 +1403,18 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid == 0) { G = gd[g]; s_status = 0; }
-    if (tid < BC - 16) {
-        Cand& C = L.cand[tid];
-        const int nn = 17 + tid;
-        for (int q = 0; q < nn; ++q) { C.e[q].aux = 1.0; C.ksel[q] = (uint8_t)q; }
-        C.m = nn;
-        Arrays A3 = A;
-        cand_order_index_call(A3, C);   // all keys equal: asc and desc compare alike
-        for (int q = 0; q < BC; ++q) s_eqperm[tid][q] = q < nn ? C.ksel[q] : (uint8_t)q;
-        for (int q = 0; q < BC; ++q) s_eqinv[tid][s_eqperm[tid][q]] = (uint8_t)q;
+    for (int base = 0; base < BC - 16; base += BATCH) {   // the candidate records serve as scratch: BATCH lengths at a time
+        const int row = base + tid;
+        if (tid < BATCH && row < BC - 16) {
+            Cand& C = L.cand[tid];
+            const int nn = 17 + row;
+            for (int q = 0; q < nn; ++q) { C.e[q].aux = 1.0; C.ksel[q] = (uint8_t)q; }
+            C.m = nn;
+            Arrays A3 = A;
+            cand_order_index_call(A3, C);   // all keys equal: asc and desc compare alike
+            for (int q = 0; q < BC; ++q) s_eqperm[row][q] = q < nn ? C.ksel[q] : (uint8_t)q;
+            for (int q = 0; q < BC; ++q) s_eqinv[row][s_eqperm[row][q]] = (uint8_t)q;
+        }
     }
     __syncthreads();
     const int32_t n = G.n;
@@ -1437,42 +1447,35 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
             while (true) {
                 b = G.bucket_base + G.minlist;
                 const int32_t cnt = A.bs_cnt[b];
-                // moved members, newest first
-                int32_t top = cnt;   // entries [0,top) not yet scanned
-                while (top > 0 && s_nc < Bcur) {
-                    int32_t a = top - 1 - tid;
-                    bool valid = false;
-                    int32_t v = -1;
-                    if (a >= 0) {
-                        int32_t sl = bs_slot(A, b, a);
-                        v = A.bs_v[sl];
-                        valid = (A.pqpos[v] == A.bs_id[sl]);
-                    }
-                    int tot;
-                    int r = block_rank(valid, L.scan, &tot);
-                    int base = s_nc;
-                    __syncthreads();
-                    if (valid && base + r < Bcur) { L.cand[base + r].v = v; L.cand[base + r].src = a; }
-                    if (tid == 0) s_nc = (base + tot < Bcur) ? base + tot : Bcur;
-                    __syncthreads();
-                    top -= NT;
-                }
-                // never-moved members, descending id
                 int32_t oc0 = A.ocur[b];
                 const int32_t oe = A.oend[b];
-                while (oc0 < oe && s_nc < Bcur) {
-                    int32_t oc = oc0 + tid;
-                    bool valid = false;
-                    int32_t v = -1;
-                    if (oc < oe) { v = A.orig_order[oc]; valid = (A.pqpos[v] == -1); }
+                // moved members, newest first, then the never-moved members in descending id.  The window of
+                // the stack that reaches its bottom is read together with the first window of the never-moved
+                // members (both load chains in flight at once, one block scan for the two).
+                int32_t top = cnt;   // entries [0,top) not yet scanned
+                while (s_nc < Bcur && (top > 0 || oc0 < oe)) {
+                    const int32_t a = top - 1 - tid;
+                    bool vs = false, vo = false;
+                    int32_t v_s = -1, v_o = -1;
+                    if (a >= 0) {
+                        int32_t sl = bs_slot(A, b, a);
+                        v_s = A.bs_v[sl];
+                        vs = (A.pqpos[v_s] == A.bs_id[sl]);
+                    }
+                    const bool last_stack = top <= NT;
+                    const int32_t oc = oc0 + tid;
+                    if (last_stack && oc < oe) { v_o = A.orig_order[oc]; vo = (A.pqpos[v_o] == -1); }
                     int tot;
-                    int r = block_rank(valid, L.scan, &tot);
-                    int base = s_nc;
+                    const int r = block_excl_scan<NWAVE>((vs ? 1 : 0) | (vo ? (1 << 16) : 0), L.scan, &tot);
+                    const int rs = r & 0xFFFF, ro = r >> 16, ts = tot & 0xFFFF, to = tot >> 16;
+                    const int base = s_nc;
                     __syncthreads();
-                    if (valid && base + r < Bcur) { L.cand[base + r].v = v; L.cand[base + r].src = ~oc; }
-                    if (tid == 0) s_nc = (base + tot < Bcur) ? base + tot : Bcur;
+                    if (vs && base + rs < Bcur) { L.cand[base + rs].v = v_s; L.cand[base + rs].src = a; }
+                    if (vo && base + ts + ro < Bcur) { L.cand[base + ts + ro].v = v_o; L.cand[base + ts + ro].src = ~oc; }
+                    if (tid == 0) s_nc = (base + ts + to < Bcur) ? base + ts + to : Bcur;
                     __syncthreads();
-                    oc0 += NT;
+                    top = top > NT ? top - NT : 0;
+                    if (last_stack) oc0 += NT;
                 }
                 if (s_nc > 0) break;
                 __syncthreads();
@@ -1840,7 +1843,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
         if (Pmax > 0) {
             // ================= P2: RNG offsets =================
             int dtot;
-            int dex = block_excl_scan(tid < Pmax ? L.cand[tid].ndraw : 0, L.scan, &dtot);
+            int dex = block_excl_scan<NWAVE>(tid < Pmax ? L.cand[tid].ndraw : 0, L.scan, &dtot);
             if (G.n_draws + dtot > A.rng_len) { if (tid == 0) s_status = ST_RNG_OVERFLOW; __syncthreads(); break; }
             // ================= P3: sampling =================
             if (tid < Pmax) {
@@ -1943,7 +1946,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                 if (j < L.cand[i].m) tcount[L.cand[i].e[j].nbr] = 0;
             }
             int mtot;
-            int mex = block_excl_scan(mycnt, L.scan, &mtot);
+            int mex = block_excl_scan<NWAVE>(mycnt, L.scan, &mtot);
             if (tid < Pmax && mex + mycnt > MCAP) atomicMin(&s_p, tid);
             __syncthreads();
             P = s_p < Pmax ? s_p : Pmax;
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(NT) void k_eliminate_batch_t(Arrays A_in, GraphDesc
                 need_thread += needk[k];
             }
             int ntot;
-            int nex = block_excl_scan(need_thread, L.scan, &ntot);
+            int nex = block_excl_scan<NWAVE>(need_thread, L.scan, &ntot);
             if (tid == 0) {
                 int32_t base = 0;
                 if (ntot > 0) {
@@ -2284,7 +2287,11 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, co
                             int32_t* batch_pos, int32_t* tcount) {
     // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
     // turn comes): it runs with 64 slots per candidate (64 candidates per round); the min-degree orders with 32.
-#define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC>), dim3(G), dim3(NT), 0, stream, A, gd, S, batch_pos, tcount); return; }
+    const bool many = G >= 512;   // more graphs than twice the CUs: the 256-thread shape, three workgroups per CU
+#define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { \
+        if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos, tcount); \
+        else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, tcount); \
+        return; }
     RLAP_CASE(OV_RANDOM, ON_ASC, 64) RLAP_CASE(OV_RANDOM, ON_DESC, 64) RLAP_CASE(OV_RANDOM, ON_RANDOM, 64)
     RLAP_CASE(OV_DEGREE, ON_ASC, 32) RLAP_CASE(OV_DEGREE, ON_DESC, 32) RLAP_CASE(OV_DEGREE, ON_RANDOM, 32)
     RLAP_CASE(OV_COARSEN, ON_ASC, 32) RLAP_CASE(OV_COARSEN, ON_DESC, 32) RLAP_CASE(OV_COARSEN, ON_RANDOM, 32)
