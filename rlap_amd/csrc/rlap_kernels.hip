@@ -13,6 +13,7 @@
 // (setup.py:26-37), and index selection depends on the exact roundings.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "rlap_core.h"
 #include "rlap_kernels.h"
@@ -2287,7 +2288,12 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, co
                             int32_t* batch_pos, int32_t* tcount) {
     // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
     // turn comes): it runs with 64 slots per candidate (64 candidates per round); the min-degree orders with 32.
-    const bool many = G >= 512;   // more graphs than twice the CUs: the 256-thread shape, three workgroups per CU
+    // more graphs than CUs: the 256-thread shape, three workgroups per CU (measured on 4096-node graphs: the same
+    // time per graph as the 1024-thread shape, which is only ahead when one graph offers more than 32 independent vertices a round)
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+    bool many = G > (unsigned)n_cu;
+    if (const char* e = std::getenv("RLAP_BATCH_SHAPE")) { if (e[0] == '2') many = true; else if (e[0] == '1') many = false; }   // diagnostic override: 256 / 1024
 #define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { \
         if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos, tcount); \
         else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, tcount); \
