@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
-    if (tid == 0) { G = gd[g]; s_status = 0; }
+    if (tid == 0) { G = gd[g]; s_status = 0; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; }
     for (int base = 0; base < BC - 16; base += BATCH) {   // the candidate records serve as scratch: BATCH lengths at a time
         const int row = base + tid;
         if (tid < BATCH && row < BC - 16) {
@@ -1441,8 +1441,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         ++rounds;
         const int32_t Bcur = (int32_t)((nelim - done) < (int64_t)BATCH ? (nelim - done) : (int64_t)BATCH);
         // ================= P0: predict the next pops =================
-        if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; }
-        __syncthreads();
+        // (the round counters were reset before the barrier that ended the previous round)
         int32_t b = 0;
         if (use_pq) {
             while (true) {
@@ -1983,6 +1982,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr);
                 }
             }
+            if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; }
             __syncthreads();
             if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
             done += 1;
@@ -2267,9 +2267,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         // ---- round epilogue ----
         if (tid < nc) batch_pos[L.cand[tid].v] = -1;
         if (tid == 0) {
-            int64_t dr = 0;
-            for (int32_t i = 0; i < P; ++i) dr += L.cand[i].ndraw;
-            G.n_draws += dr;
+            G.n_draws = L.cand[P - 1].draw0 + L.cand[P - 1].ndraw;   // offsets are a running sum (P2)
+            s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0;
         }
         done += P;
         __syncthreads();
