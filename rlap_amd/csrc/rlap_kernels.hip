@@ -1858,7 +1858,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     if (i >= Pmax) continue;
                     if (j < L.cand[i].m - 1) cand_pick(A, L.cand[i], j);
                 }
-                if (tid < Pmax) cand_recur(A, L.cand[tid]);   // touches e[].val only
+                // the recurrence (touches e[].val only) runs on the LAST waves, whose share of the picks above is
+                // empty unless the round is nearly full: it overlaps with the other waves' picks
+                if (tid >= NT - BATCH && tid - (NT - BATCH) < Pmax) cand_recur(A, L.cand[tid - (NT - BATCH)]);
             }
             __syncthreads();
             PHASE_STAMP(3);
