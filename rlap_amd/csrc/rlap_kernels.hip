@@ -2005,6 +2005,16 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             if (C.m >= 1) A.e_val[C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin] = 0;
             if (MERGE) for (int32_t q = 0; q < C.nkill; ++q) A.e_val[C.e[C.m + q].twin] = 0;   // merged multi-edges (:289)
         }
+        // append cursors of the targets shared by several candidates: loaded now (one group head per thread), used
+        // after the pool bump below
+        const int32_t ncont_c = s_ncont < CCAP ? s_ncont : CCAP;
+        bool chead = false;
+        int32_t ca0 = 0, cchunk0 = 0;
+        if (tid < ncont_c) {
+            const CRec me = L.csorted[tid];
+            chead = (tid == 0 || L.csorted[tid - 1].x != me.x) && me.i < P;
+            if (chead) { ca0 = A.app_cnt[me.x]; cchunk0 = A.app_chunk[me.x]; }
+        }
         // targets touched by one candidate only: one thread per (candidate, target); two passes so that
         // all loads are in flight together and the pool is bumped once per round
         {
@@ -2086,13 +2096,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         }
         // targets shared by several candidates: one thread walks the target's records in candidate order
         {
-            const int32_t ncont = s_ncont < CCAP ? s_ncont : CCAP;
+            const int32_t ncont = ncont_c;   // <= CCAP < NT: one record per thread
             const CRec* csorted = L.csorted;
-            for (int32_t q = tid; q < ncont; q += NT) {
-                if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;
+            if (chead) {
+                const int32_t q = tid;
                 const int32_t x = csorted[q].x;
-                if (csorted[q].i >= P) continue;
-                int32_t a = A.app_cnt[x], chunk = A.app_chunk[x];
+                int32_t a = ca0, chunk = cchunk0;
                 const int32_t a_before = a;
                 int32_t key_final = 0, mvseq = -1;
                 for (int32_t r = q; r < ncont && csorted[r].x == x && csorted[r].i < P; ++r) {
@@ -2220,43 +2229,33 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     __syncthreads();
                 }
             }
-            // ---- allocate new stack chunks, then write the entries ----
-            for (int32_t r = tid; r < nmoves; r += NT) {
-                int32_t lst = (int32_t)(L.mkey[r] >> 32);
-                int32_t bk = G.bucket_base + lst;
-                int32_t a = A.bs_cnt[bk] + (r - L.hidx[r]);
-                int c = bs_chunk_of(a);
-                if (c >= A.bs_alloc[bk] && a == bs_chunk_start(c)) {
-                    int32_t need = bs_chunk_cap(c);
+            // ---- allocate new stack chunks, then write the entries (nmoves <= MCAP = NT: one move per thread; the
+            //      stack height and chunk count read once and kept in registers over the three steps) ----
+            const bool mine = tid < nmoves;
+            int32_t bk = 0, a_my = 0, c_my = 0, al_my = 0;
+            if (mine) {
+                bk = G.bucket_base + (int32_t)(L.mkey[tid] >> 32);
+                a_my = A.bs_cnt[bk] + (tid - L.hidx[tid]);
+                al_my = A.bs_alloc[bk];
+                c_my = bs_chunk_of(a_my);
+                if (c_my >= al_my && a_my == bs_chunk_start(c_my)) {
+                    int32_t need = bs_chunk_cap(c_my);
                     int32_t base = atomicAdd(A.bs_pool_top, need);
                     if (base < 0 || base > A.bs_pool_cap - need) status = ST_LOG_OVERFLOW;
-                    else A.bs_dir[(int64_t)bk * BDIR + c] = base;
+                    else A.bs_dir[(int64_t)bk * BDIR + c_my] = base;
                 }
             }
             if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_LOG_OVERFLOW; __syncthreads(); break; }
             const int32_t id0 = G.push_cnt;
-            for (int32_t r = tid; r < nmoves; r += NT) {
-                int32_t lst = (int32_t)(L.mkey[r] >> 32);
-                int32_t bk = G.bucket_base + lst;
-                int32_t a = A.bs_cnt[bk] + (r - L.hidx[r]);
-                int c = bs_chunk_of(a);
-                int32_t sl = A.bs_dir[(int64_t)bk * BDIR + c] + (a - bs_chunk_start(c));
-                int32_t v = L.mval[r];
-                A.bs_v[sl] = v; A.bs_id[sl] = id0 + r;
-                A.pqpos[v] = id0 + r;
-                L.hidx[r] = a;   // remember the position for the group tail below
-            }
-            __syncthreads();
-            for (int32_t r = tid; r < nmoves; r += NT) {
-                bool tail = (r == nmoves - 1) || ((uint32_t)(L.mkey[r + 1] >> 32) != (uint32_t)(L.mkey[r] >> 32));
-                if (tail) {
-                    int32_t lst = (int32_t)(L.mkey[r] >> 32);
-                    int32_t bk = G.bucket_base + lst;
-                    int32_t a = L.hidx[r];
-                    int c = bs_chunk_of(a);
-                    int32_t al = A.bs_alloc[bk];
-                    A.bs_cnt[bk] = a + 1;
-                    if (c + 1 > al) A.bs_alloc[bk] = c + 1;
+            if (mine) {
+                int32_t sl = A.bs_dir[(int64_t)bk * BDIR + c_my] + (a_my - bs_chunk_start(c_my));
+                int32_t v = L.mval[tid];
+                A.bs_v[sl] = v; A.bs_id[sl] = id0 + tid;
+                A.pqpos[v] = id0 + tid;
+                const bool tail = (tid == nmoves - 1) || ((uint32_t)(L.mkey[tid + 1] >> 32) != (uint32_t)(L.mkey[tid] >> 32));
+                if (tail) {   // last move of its bucket group: the stack's new height (and chunk count)
+                    A.bs_cnt[bk] = a_my + 1;
+                    if (c_my + 1 > al_my) A.bs_alloc[bk] = c_my + 1;
                 }
             }
             if (tid == 0) {
