@@ -1284,9 +1284,14 @@ struct CRec { int32_t x, i, j; };
 template <int BC, int NTT>
 struct BatchLdsT {
     CandT<BC> cand[4 * NTT / BC];
-    uint64_t mkey[NTT];       // PQ moves per round: one per thread, sorted in registers + LDS
-    int32_t mval[NTT];
-    int32_t hidx[NTT];
+    union {
+        struct {
+            uint64_t mkey[NTT];   // PQ moves per round: one per thread, sorted in registers + LDS
+            int32_t mval[NTT];
+            int32_t hidx[NTT];
+        };
+        int32_t hcnt[4 * NTT];    // before the commit: counts of the target hash table (keys over pslot)
+    };
     int32_t pslot[4 * NTT];   // slot of the entry position p of candidate i appends (commit phase)
     CRec cont[NTT / 2];       // contended (target, candidate) records per round
     CRec csorted[NTT / 2];
@@ -1384,6 +1389,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     constexpr int SLOTS = PASSES * NT; // candidates x slots per round
     constexpr int MCAP = NT;           // PQ moves per round
     constexpr int CCAP = NT / 2;       // contended records per round
+    constexpr int HBITS = (SLOTS == 4096) ? 12 : (SLOTS == 2048) ? 11 : 10;   // log2(SLOTS): size of the target hash table
+    static_assert((1 << HBITS) == SLOTS, "hash table = one place per slot");
+    (void)tcount;
     // BC slots per candidate: a group of BC lanes (half a wave or a whole wave) works on one candidate
     constexpr int BCAP = BC;
     constexpr int BATCH = SLOTS / BC;
@@ -1824,6 +1832,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         }
         __syncthreads();
         PHASE_STAMP(1);
+        // targets shared by several candidates are found with an LDS hash table (keys over pslot, counts over the
+        // move arrays: both idle until the commit); cleared here, filled and read in P4 behind later barriers
+        int32_t* const hkeys = L.pslot;
+        int32_t* const hcnt = L.hcnt;
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) { hkeys[k * NT + tid] = -1; hcnt[k * NT + tid] = 0; }
         // ================= P1b: first candidate that depends on an earlier one =================
         if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);
         #pragma unroll 1
@@ -1869,7 +1883,17 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                 if (i >= Pmax) continue;
-                if (j < L.cand[i].m) atomicAdd(&tcount[L.cand[i].e[j].nbr], 1);
+                if (j < L.cand[i].m) {
+                    const int32_t x = L.cand[i].e[j].nbr;
+                    uint32_t hh = ((uint32_t)x * 2654435761u) >> (32 - HBITS);
+                    while (true) {   // linear probing; at most SLOTS distinct keys in SLOTS places
+                        const int32_t cur = hkeys[hh];
+                        if (cur == x) break;
+                        if (cur == -1) { const int32_t old = atomicCAS(&hkeys[hh], -1, x); if (old == -1 || old == x) break; }
+                        hh = (hh + 1) & (SLOTS - 1);
+                    }
+                    atomicAdd(&hcnt[hh], 1);
+                }
             }
             __syncthreads();
             #pragma unroll 1
@@ -1879,7 +1903,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 Cand& C = L.cand[i];
                 if (j >= C.m) continue;
                 const int32_t x = C.e[j].nbr;
-                const int32_t tc = ld_agent(&tcount[x]);
+                uint32_t hh = ((uint32_t)x * 2654435761u) >> (32 - HBITS);
+                while (hkeys[hh] != x) hh = (hh + 1) & (SLOTS - 1);
+                const int32_t tc = hcnt[hh];
                 const int32_t key0 = use_pq ? A.key[x] : 1;
                 TRes& R = ent_tres(C.e[j]);
                 if (tc > 1) {
@@ -1939,13 +1965,6 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     if (R.mv >= 0) { ++mycnt; if (pq_list_of(R.key_after, n) <= G.minlist) pre = true; }
                 }
                 if (pre) atomicMin(&s_p, tid + 1);
-            }
-            // tcount back to zero for the next round
-            #pragma unroll 1
-            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
-                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
-                if (i >= Pmax) continue;
-                if (j < L.cand[i].m) tcount[L.cand[i].e[j].nbr] = 0;
             }
             int mtot;
             int mex = block_excl_scan<NWAVE>(mycnt, L.scan, &mtot);
