@@ -654,6 +654,7 @@ struct CandT : CandPad<BC> {
     int32_t cp1;      // colptr[v+1]
     int32_t acnt;     // appended entries
     int32_t ext;      // slots to read (appended + CSR), dead ones included
+    int32_t nmv;      // PQ moves this candidate causes (counted during the replay; bounds the round's move list)
     int32_t nkill;    // merged multi-edges (o_v = random, 64-slot form): e[m .. m+nkill) hold the twins that die (:289)
     int32_t cb[BC <= 32 ? 3 : 4];   // bases of the appended chunks
     int64_t draw0;    // first uniform
@@ -711,7 +712,7 @@ RLAP_HD bool cand_merges_multi_edges(const Arrays& A) { return CT::CAP == 64 && 
 // threads: cand_meta (one per candidate), cand_load (one per slot), cand_finish.
 template <class CT>
 RLAP_HD void cand_meta(const Arrays& A, int32_t v, CT& C) {
-    C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0; C.nkill = 0;
+    C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0; C.nkill = 0; C.nmv = 0;
     int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
     int32_t acnt = A.app_cnt[v];
     C.cp1 = cp1; C.acnt = acnt; C.ext = (cp1 - cp0) + acnt;
@@ -848,17 +849,28 @@ RLAP_HD void cand_sample(const Arrays& A, CT& C) {
 // (valid while every intermediate key stays <= n, where each change moves the
 // vertex; otherwise *complex is set).  Returns the new key; *mv = op number of
 // the last move or -1; *cnt = pushes into the target's column.
+// Split in two: what does not depend on the key (pushes into the target's column, position of the last one) ...
 template <class CT>
-RLAP_HD int32_t cand_replay(const Arrays& A, const CT& C, int32_t j, int32_t key0, int32_t n, bool allow_last_dec,
-                            int* mv, int* cnt, bool* complex) {
+RLAP_HD void cand_replay_pre(const Arrays& A, const CT& C, int32_t j, int* cnt, int* last_inc) {
+    const int32_t m = C.m;
+    int32_t li = -1, c = 0;
+    if (A.o_v == OV_COARSEN) {
+        if (j == C.koff) c = m - 1;
+    } else {
+        for (int32_t q = 0; q < m - 1; ++q) if (C.ksel[q] == j) { ++c; li = q; }
+    }
+    *cnt = c; *last_inc = li;
+}
+// ... and the key arithmetic on top of it (a target shared by several candidates chains it through their records)
+template <class CT>
+RLAP_HD int32_t cand_replay_post(const Arrays& A, const CT& C, int32_t j, int32_t key0, int32_t n, bool allow_last_dec,
+                                 int c, int last_inc, int* mv, bool* complex) {
     const int32_t m = C.m;
     int32_t key = key0;
-    int32_t last_inc = -1, c = 0;
     *mv = -1;
     if (A.o_v == OV_COARSEN) {
         if (j == C.koff) {
             if (key != 1) { key -= 1; *mv = m; }            // :882, op number m
-            c = m - 1;
             if (c > 0) {
                 key += c;
                 int32_t lastj = (C.koff == m - 1) ? m - 2 : m - 1;
@@ -866,13 +878,19 @@ RLAP_HD int32_t cand_replay(const Arrays& A, const CT& C, int32_t j, int32_t key
             }
         }
     } else {
-        for (int32_t q = 0; q < m - 1; ++q) if (C.ksel[q] == j) { ++c; last_inc = q; }
         if (c > 0) { key += c; *mv = m + last_inc; }          // :399, op numbers m + q
         if (j == m - 1 && allow_last_dec && key != 1) { key -= 1; *mv = 2 * m; }  // :427
     }
-    *cnt = c;
     if (key0 > n || key0 + c > n) *complex = true;
     return key;
+}
+template <class CT>
+RLAP_HD int32_t cand_replay(const Arrays& A, const CT& C, int32_t j, int32_t key0, int32_t n, bool allow_last_dec,
+                            int* mv, int* cnt, bool* complex) {
+    int c, li;
+    cand_replay_pre(A, C, j, &c, &li);
+    *cnt = c;
+    return cand_replay_post(A, C, j, key0, n, allow_last_dec, c, li, mv, complex);
 }
 
 }  // namespace rlap

@@ -1909,7 +1909,10 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 const int32_t key0 = use_pq ? A.key[x] : 1;
                 TRes& R = ent_tres(C.e[j]);
                 if (tc > 1) {
-                    R.flags = TF_CONTENDED; R.mv = -1; R.c = 0; R.key_after = 0;
+                    // the key-independent half of the replay now, in parallel; the walk below chains the keys
+                    int c0, li0;
+                    cand_replay_pre(A, C, j, &c0, &li0);
+                    R.flags = TF_CONTENDED; R.mv = (int16_t)li0; R.c = (uint8_t)c0; R.key_after = 0;
                     int32_t q = atomicAdd(&s_ncont, 1);
                     if (q < CCAP) { L.cont[q].x = x; L.cont[q].i = i; L.cont[q].j = j; }
                     else atomicMin(&s_p, i);     // record list full: stop the round before this candidate
@@ -1920,7 +1923,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 int32_t k2 = cand_replay(A, C, j, key0, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
                 if (!use_pq) { mv = -1; cx = false; }
                 R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c; R.flags = 0;
-                if (cx) atomicOr(&C.flags, CF_COMPLEX);
+                if (cx) atomicMin(&s_p, i);   // keys beyond n: this candidate goes to the single-vertex path
+                if (mv >= 0) {
+                    atomicAdd(&C.nmv, 1);
+                    if (pq_list_of(k2, n) <= G.minlist) atomicMin(&s_p, i + 1);   // pre-empts the predicted order: last of the round
+                }
             }
             __syncthreads();
             // contended records: order by (x, i) with a rank sort (keys are distinct), then replay each group in order
@@ -1944,31 +1951,31 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 for (int32_t r = q; r < ncont && csorted[r].x == x; ++r) {
                     Cand& C = L.cand[csorted[r].i];
                     const bool allow_last = (done + csorted[r].i + 1) + 1 < (int64_t)n;
-                    int mv, c; bool cx = false;
-                    int32_t k2 = cand_replay(A, C, csorted[r].j, key, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
-                    if (!use_pq) { mv = -1; cx = false; }
                     TRes& R = ent_tres(C.e[csorted[r].j]);
-                    R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c;
-                    if (cx) atomicOr(&C.flags, CF_COMPLEX);
+                    int mv; bool cx = false;
+                    int32_t k2 = cand_replay_post(A, C, csorted[r].j, key, use_pq ? n : 0x7FFFFFFF, allow_last, (int)R.c, (int)R.mv, &mv, &cx);
+                    if (!use_pq) { mv = -1; cx = false; }
+                    R.key_after = k2; R.mv = (int16_t)mv;
+                    if (cx) atomicMin(&s_p, csorted[r].i);
+                    if (mv >= 0) {
+                        atomicAdd(&C.nmv, 1);
+                        if (pq_list_of(k2, n) <= G.minlist) atomicMin(&s_p, csorted[r].i + 1);
+                    }
                     key = k2;
                 }
             }
             __syncthreads();
-            // ================= P: first pre-empting / complex candidate; bound the number of moves =================
-            int mycnt = 0;
-            if (tid < Pmax) {
-                Cand& C = L.cand[tid];
-                if (C.flags & CF_COMPLEX) atomicMin(&s_p, tid);
-                bool pre = false;
-                for (int32_t j = 0; j < C.m; ++j) {
-                    TRes& R = ent_tres(C.e[j]);
-                    if (R.mv >= 0) { ++mycnt; if (pq_list_of(R.key_after, n) <= G.minlist) pre = true; }
-                }
-                if (pre) atomicMin(&s_p, tid + 1);
+            // ================= P: the first pre-empting / complex candidate was noted during the replay; bound the
+            // number of moves (candidates sit in the first two waves: a wave scan and one word through LDS) =================
+            {
+                const int mycnt = tid < Pmax ? L.cand[tid].nmv : 0;
+                int incl = mycnt;
+                for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                if (tid == 63) L.scan[0] = incl;
+                __syncthreads();
+                static_assert(BATCH <= 128, "candidates live in waves 0 and 1");
+                if (tid < Pmax && incl + (tid >= 64 ? L.scan[0] : 0) > MCAP) atomicMin(&s_p, tid);
             }
-            int mtot;
-            int mex = block_excl_scan<NWAVE>(mycnt, L.scan, &mtot);
-            if (tid < Pmax && mex + mycnt > MCAP) atomicMin(&s_p, tid);
             __syncthreads();
             P = s_p < Pmax ? s_p : Pmax;
             PHASE_STAMP(4);
