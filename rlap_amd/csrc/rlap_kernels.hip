@@ -1293,6 +1293,7 @@ struct BatchLdsT {
         int32_t hcnt[4 * NTT];    // before the commit: counts of the target hash table (keys over pslot)
     };
     int32_t pslot[4 * NTT];   // slot of the entry position p of candidate i appends (commit phase)
+    unsigned long long cmask[4 * NTT / BC];   // per candidate: which op numbers (mv - m) end in a PQ move -> order of the moves
     CRec cont[NTT / 2];       // contended (target, candidate) records per round
     CRec csorted[NTT / 2];
     int32_t scan[NTT / 64 + 8];
@@ -1405,7 +1406,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     A.o_n = ON;
     __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
-    __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status;
+    __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow;
     __shared__ uint8_t s_eqperm[BC - 16][BC];   // std::sort's permutation of n = 17..BC all-equal keys
     __shared__ uint8_t s_eqinv[BC - 16][BC];    // its inverse: final position of the entry with id-rank r
     BatchLds& L = sh.b;
@@ -1838,6 +1839,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         int32_t* const hcnt = L.hcnt;
 #pragma unroll
         for (int k = 0; k < PASSES; ++k) { hkeys[k * NT + tid] = -1; hcnt[k * NT + tid] = 0; }
+        if (tid < BATCH) L.cmask[tid] = 0ull;
         // ================= P1b: first candidate that depends on an earlier one =================
         if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);
         #pragma unroll 1
@@ -2112,6 +2114,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 }
                 if (mvd) {
                     A.key[xk[k]] = Rk[k].key_after;
+                    atomicOr(&L.cmask[i], 1ull << (Rk[k].mv - L.cand[i].m));
                     int32_t q = qbase + __popcll(mvmask & lanemask_lt(lane));
                     if (q < MCAP) {
                         L.mkey[q] = ((uint64_t)(uint32_t)pq_list_of(Rk[k].key_after, n) << 32) | (uint32_t)((i << 8) | Rk[k].mv);
@@ -2141,6 +2144,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 if (use_pq) {
                     A.key[x] = key_final;
                     if (mvseq >= 0) {
+                        atomicOr(&L.cmask[mvseq >> 8], 1ull << ((mvseq & 0xFF) - L.cand[mvseq >> 8].m));
                         int32_t qq = atomicAdd(&s_nmoves, 1);
                         if (qq < MCAP) {
                             L.mkey[qq] = ((uint64_t)(uint32_t)pq_list_of(key_final, n) << 32) | (uint32_t)mvseq;
@@ -2169,99 +2173,204 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         const int32_t nmoves = s_nmoves;
         if (nmoves > MCAP) { if (tid == 0) s_status = ST_INTERNAL; __syncthreads(); break; }
         if (use_pq && nmoves > 0) {
-            // ---- sort the moves by (bucket, op order): bitonic, one element per thread; strides < 64 stay
-            //      inside the wave (shuffles), only the larger strides go through LDS.  Keys are packed
-            //      into 32 bits ((bucket - lowest bucket) << 15 | candidate << 8 | op) when they fit ----
+            static_assert(BC == 32 || OV == OV_RANDOM, "op numbers mv - m fit a 64-bit mask for 32-slot candidates");
+            // ---- order of the moves = (bucket, candidate, op).  No sort: a move's place in (candidate, op) order is
+            //      the candidates' move counts summed before it plus the rank of its op bit in its candidate's mask;
+            //      the moves are laid out in that order, then each finds its rank inside its bucket by counting
+            //      (64 buckets above the lowest through a per-wave table, the few beyond -- hubs -- by comparing
+            //      among themselves).  Falls back to the bitonic sort when more than 64 moves go beyond. ----
+            const bool mine = tid < nmoves;
+            int32_t list_my = 0, x_my = -1, rank_my = 0, pos_my = 0;
+            bool tail_my = false;
+            uint32_t bmin = 0xFFFFFFFFu;
+            bool fallback = false;
             {
-                uint64_t kq = tid < nmoves ? L.mkey[tid] : ~0ull;
-                int32_t vq = tid < nmoves ? L.mval[tid] : -1;
-                uint32_t bmin = tid < nmoves ? (uint32_t)(kq >> 32) : 0xFFFFFFFFu, bmax = tid < nmoves ? (uint32_t)(kq >> 32) : 0u;
-                for (int off = 32; off > 0; off >>= 1) { bmin = min(bmin, (uint32_t)__shfl_xor((int)bmin, off)); bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, off)); }
-                if (lane == 0) { L.scan[tid >> 6] = (int32_t)bmin; L.hidx[tid >> 6] = (int32_t)bmax; }
+                const uint64_t kq0 = mine ? L.mkey[tid] : 0ull;
+                const int32_t x0 = mine ? L.mval[tid] : -1;
+                const int32_t seq = (int32_t)(kq0 & 0x7FFFull);
+                const int32_t ci = seq >> 8, cmv = seq & 0xFF;
+                if (mine) bmin = (uint32_t)(kq0 >> 32);
+                for (int off = 32; off > 0; off >>= 1) bmin = min(bmin, (uint32_t)__shfl_xor((int)bmin, off));
+                if (lane == 0) L.scan[tid >> 6] = (int32_t)bmin;
+                const int cnt_i = tid < P ? __popcll(L.cmask[tid]) : 0;
+                int incl = cnt_i;
+                for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+                if (tid == 63) L.scan[NWAVE] = incl;
                 __syncthreads();
-                for (int w = 0; w < NWAVE; ++w) { bmin = min(bmin, (uint32_t)L.scan[w]); bmax = max(bmax, (uint32_t)L.hidx[w]); }
-                int32_t npow = 64;
-                while (npow < nmoves) npow <<= 1;
+                for (int w = 0; w < NWAVE; ++w) bmin = min(bmin, (uint32_t)L.scan[w]);
+                if (tid < P) L.hidx[tid] = incl - cnt_i + (tid >= 64 ? L.scan[NWAVE] : 0);
+                int32_t* const wtab = L.pslot;            // [NWAVE][64] move counts per (wave, bucket above the lowest); pslot is idle now
+                wtab[tid] = 0;
+                if (tid == 0) s_nhigh = 0;
                 __syncthreads();
-                if (bmax - bmin < (1u << 16)) {
-                    uint32_t k32 = tid < nmoves ? ((((uint32_t)(kq >> 32) - bmin) << 15) | ((uint32_t)kq & 0x7FFFu)) : 0xFFFFFFFFu;
-                    uint32_t* lk = reinterpret_cast<uint32_t*>(L.mkey);
-                    for (int32_t k = 2; k <= npow; k <<= 1) {
-                        for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                            const bool take_min = (((tid & jj) == 0) == ((tid & k) == 0));
-                            uint32_t ko; int32_t vo;
-                            if (jj >= 64) {
-                                lk[tid] = k32; L.mval[tid] = vq;
-                                __syncthreads();
-                                ko = lk[tid ^ jj]; vo = L.mval[tid ^ jj];
-                                __syncthreads();
-                            } else {
-                                ko = (uint32_t)__shfl_xor((int)k32, jj);
-                                vo = __shfl_xor(vq, jj);
-                            }
-                            const bool swap = take_min ? (ko < k32) : (ko > k32);
-                            if (swap) { k32 = ko; vq = vo; }
-                        }
-                    }
-                    __syncthreads();
-                    kq = (k32 == 0xFFFFFFFFu) ? ~0ull : ((((uint64_t)((k32 >> 15) + bmin)) << 32) | (uint64_t)(k32 & 0x7FFFu));
-                } else {
-                    for (int32_t k = 2; k <= npow; k <<= 1) {
-                        for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
-                            const bool take_min = (((tid & jj) == 0) == ((tid & k) == 0));
-                            uint64_t ko; int32_t vo;
-                            if (jj >= 64) {
-                                L.mkey[tid] = kq; L.mval[tid] = vq;
-                                __syncthreads();
-                                ko = L.mkey[tid ^ jj]; vo = L.mval[tid ^ jj];
-                                __syncthreads();
-                            } else {
-                                uint32_t lo32 = (uint32_t)kq, hi32 = (uint32_t)(kq >> 32);
-                                uint32_t olo = (uint32_t)__shfl_xor((int)lo32, jj), ohi = (uint32_t)__shfl_xor((int)hi32, jj);
-                                ko = ((uint64_t)ohi << 32) | olo;
-                                vo = __shfl_xor(vq, jj);
-                            }
-                            const bool swap = take_min ? (ko < kq) : (ko > kq);
-                            if (swap) { kq = ko; vq = vo; }
-                        }
+                uint32_t* const lst32 = reinterpret_cast<uint32_t*>(L.mkey);
+                if (mine) {
+                    const int32_t idx = L.hidx[ci] + __popcll(L.cmask[ci] & ((1ull << (cmv - L.cand[ci].m)) - 1ull));
+                    lst32[idx] = (uint32_t)(kq0 >> 32);
+                    L.mval[idx] = x0;
+                }
+                __syncthreads();
+                if (mine) { list_my = (int32_t)lst32[tid]; x_my = L.mval[tid]; }
+                const uint32_t brel = (uint32_t)list_my - bmin;
+                const bool low = mine && brel < 64u, high = mine && brel >= 64u;
+                int32_t* const btot = L.pslot + NT;       // [64] moves per low bucket
+                int32_t* const bstart = L.pslot + NT + 64;   // [64] first sorted position of a low bucket
+                int32_t* const hl_list = L.pslot + NT + 128; // [64] buckets of the moves beyond
+                int32_t* const hl_idx = L.pslot + NT + 192;  // [64] their places in (candidate, op) order
+                int rank_w = 0;
+                {
+                    const uint64_t lt = lanemask_lt(lane);
+                    uint64_t rem = __ballot(low);
+                    while (rem) {
+                        const int l = __builtin_ctzll(rem);
+                        const uint32_t bb = (uint32_t)__shfl((int)brel, l);
+                        const uint64_t same = __ballot(low && brel == bb);
+                        if (low && brel == bb) rank_w = __popcll(same & lt);
+                        if (lane == l) wtab[(tid >> 6) * 64 + bb] = __popcll(same);
+                        rem &= ~same;
                     }
                 }
-                L.mkey[tid] = kq; L.mval[tid] = vq;
+                if (high) { const int32_t q = atomicAdd(&s_nhigh, 1); if (q < 64) { hl_list[q] = list_my; hl_idx[q] = tid; } }
                 __syncthreads();
+                const int32_t nhigh = s_nhigh;
+                fallback = nhigh > 64;
+                if (!fallback) {
+                    if (tid < 64) {
+                        int acc = 0;
+                        for (int w = 0; w < NWAVE; ++w) { const int t = wtab[w * 64 + tid]; wtab[w * 64 + tid] = acc; acc += t; }
+                        btot[tid] = acc;
+                        int inc2 = acc;
+                        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc2, off); if (lane >= off) inc2 += t; }
+                        bstart[tid] = inc2 - acc;
+                        if (tid == 63) s_nlow = inc2;
+                    }
+                    __syncthreads();
+                    if (low) {
+                        rank_my = wtab[(tid >> 6) * 64 + brel] + rank_w;
+                        pos_my = bstart[brel] + rank_my;
+                        tail_my = rank_my == btot[brel] - 1;
+                    } else if (high) {
+                        int32_t before = 0, same_b = 0, cntb = 0;
+                        for (int32_t q = 0; q < nhigh; ++q) {
+                            const int32_t l2 = hl_list[q], t2 = hl_idx[q];
+                            before += (l2 < list_my || (l2 == list_my && t2 < tid)) ? 1 : 0;
+                            if (l2 == list_my) { ++cntb; same_b += (t2 < tid) ? 1 : 0; }
+                        }
+                        rank_my = same_b;
+                        pos_my = s_nlow + before;
+                        tail_my = rank_my == cntb - 1;
+                    }
+                } else {
+                    // the moves sit in (candidate, op) order: their place stands in for the (candidate, op) key
+                    __syncthreads();
+                    L.mkey[tid] = mine ? (((uint64_t)(uint32_t)list_my << 32) | (uint32_t)tid) : ~0ull;
+                    L.mval[tid] = x_my;
+                    __syncthreads();
+                }
+            }
+            if (fallback) {
+                // ---- sort the moves by (bucket, op order): bitonic, one element per thread; strides < 64 stay
+                //      inside the wave (shuffles), only the larger strides go through LDS.  Keys are packed
+                //      into 32 bits ((bucket - lowest bucket) << 15 | candidate << 8 | op) when they fit ----
+                {
+                    uint64_t kq = tid < nmoves ? L.mkey[tid] : ~0ull;
+                    int32_t vq = tid < nmoves ? L.mval[tid] : -1;
+                    uint32_t bmin = tid < nmoves ? (uint32_t)(kq >> 32) : 0xFFFFFFFFu, bmax = tid < nmoves ? (uint32_t)(kq >> 32) : 0u;
+                    for (int off = 32; off > 0; off >>= 1) { bmin = min(bmin, (uint32_t)__shfl_xor((int)bmin, off)); bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, off)); }
+                    if (lane == 0) { L.scan[tid >> 6] = (int32_t)bmin; L.hidx[tid >> 6] = (int32_t)bmax; }
+                    __syncthreads();
+                    for (int w = 0; w < NWAVE; ++w) { bmin = min(bmin, (uint32_t)L.scan[w]); bmax = max(bmax, (uint32_t)L.hidx[w]); }
+                    int32_t npow = 64;
+                    while (npow < nmoves) npow <<= 1;
+                    __syncthreads();
+                    if (bmax - bmin < (1u << 16)) {
+                        uint32_t k32 = tid < nmoves ? ((((uint32_t)(kq >> 32) - bmin) << 15) | ((uint32_t)kq & 0x7FFFu)) : 0xFFFFFFFFu;
+                        uint32_t* lk = reinterpret_cast<uint32_t*>(L.mkey);
+                        for (int32_t k = 2; k <= npow; k <<= 1) {
+                            for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                                const bool take_min = (((tid & jj) == 0) == ((tid & k) == 0));
+                                uint32_t ko; int32_t vo;
+                                if (jj >= 64) {
+                                    lk[tid] = k32; L.mval[tid] = vq;
+                                    __syncthreads();
+                                    ko = lk[tid ^ jj]; vo = L.mval[tid ^ jj];
+                                    __syncthreads();
+                                } else {
+                                    ko = (uint32_t)__shfl_xor((int)k32, jj);
+                                    vo = __shfl_xor(vq, jj);
+                                }
+                                const bool swap = take_min ? (ko < k32) : (ko > k32);
+                                if (swap) { k32 = ko; vq = vo; }
+                            }
+                        }
+                        __syncthreads();
+                        kq = (k32 == 0xFFFFFFFFu) ? ~0ull : ((((uint64_t)((k32 >> 15) + bmin)) << 32) | (uint64_t)(k32 & 0x7FFFu));
+                    } else {
+                        for (int32_t k = 2; k <= npow; k <<= 1) {
+                            for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                                const bool take_min = (((tid & jj) == 0) == ((tid & k) == 0));
+                                uint64_t ko; int32_t vo;
+                                if (jj >= 64) {
+                                    L.mkey[tid] = kq; L.mval[tid] = vq;
+                                    __syncthreads();
+                                    ko = L.mkey[tid ^ jj]; vo = L.mval[tid ^ jj];
+                                    __syncthreads();
+                                } else {
+                                    uint32_t lo32 = (uint32_t)kq, hi32 = (uint32_t)(kq >> 32);
+                                    uint32_t olo = (uint32_t)__shfl_xor((int)lo32, jj), ohi = (uint32_t)__shfl_xor((int)hi32, jj);
+                                    ko = ((uint64_t)ohi << 32) | olo;
+                                    vo = __shfl_xor(vq, jj);
+                                }
+                                const bool swap = take_min ? (ko < kq) : (ko > kq);
+                                if (swap) { kq = ko; vq = vo; }
+                            }
+                        }
+                    }
+                    L.mkey[tid] = kq; L.mval[tid] = vq;
+                    __syncthreads();
+                }
+                // ---- bucket-group head index of every move (inclusive max scan) ----
+                {
+                    int32_t carry = 0;
+                    for (int32_t c0 = 0; c0 < nmoves; c0 += NT) {
+                        int32_t r = c0 + tid;
+                        int32_t hv = -1;
+                        if (r < nmoves) {
+                            uint32_t bk = (uint32_t)(L.mkey[r] >> 32);
+                            bool head = (r == 0) || ((uint32_t)(L.mkey[r - 1] >> 32) != bk);
+                            hv = head ? r : -1;
+                        }
+                        int32_t incl = hv;
+                        for (int off = 1; off < 64; off <<= 1) { int32_t tt = __shfl_up(incl, off); if (lane >= off) incl = max(incl, tt); }
+                        if (lane == 63) L.scan[tid >> 6] = incl;
+                        __syncthreads();
+                        int32_t pre = carry;
+                        for (int w = 0; w < (tid >> 6); ++w) pre = max(pre, L.scan[w]);
+                        incl = max(incl, pre);
+                        if (r < nmoves) L.hidx[r] = incl;
+                        int32_t nc2 = carry;
+                        for (int w = 0; w < NWAVE; ++w) nc2 = max(nc2, L.scan[w]);
+                        carry = nc2;
+                        __syncthreads();
+                    }
+                }
+                if (mine) {
+                    list_my = (int32_t)(L.mkey[tid] >> 32);
+                    x_my = L.mval[tid];
+                    rank_my = tid - L.hidx[tid];
+                    pos_my = tid;
+                    tail_my = (tid == nmoves - 1) || ((uint32_t)(L.mkey[tid + 1] >> 32) != (uint32_t)(L.mkey[tid] >> 32));
+                    if (tid == 0) bmin = (uint32_t)list_my;
+                }
+                bmin = (uint32_t)(L.mkey[0] >> 32);
             }
             PHASE_STAMP(7);
-            // ---- bucket-group head index of every move (inclusive max scan) ----
-            {
-                int32_t carry = 0;
-                for (int32_t c0 = 0; c0 < nmoves; c0 += NT) {
-                    int32_t r = c0 + tid;
-                    int32_t hv = -1;
-                    if (r < nmoves) {
-                        uint32_t bk = (uint32_t)(L.mkey[r] >> 32);
-                        bool head = (r == 0) || ((uint32_t)(L.mkey[r - 1] >> 32) != bk);
-                        hv = head ? r : -1;
-                    }
-                    int32_t incl = hv;
-                    for (int off = 1; off < 64; off <<= 1) { int32_t tt = __shfl_up(incl, off); if (lane >= off) incl = max(incl, tt); }
-                    if (lane == 63) L.scan[tid >> 6] = incl;
-                    __syncthreads();
-                    int32_t pre = carry;
-                    for (int w = 0; w < (tid >> 6); ++w) pre = max(pre, L.scan[w]);
-                    incl = max(incl, pre);
-                    if (r < nmoves) L.hidx[r] = incl;
-                    int32_t nc2 = carry;
-                    for (int w = 0; w < NWAVE; ++w) nc2 = max(nc2, L.scan[w]);
-                    carry = nc2;
-                    __syncthreads();
-                }
-            }
-            // ---- allocate new stack chunks, then write the entries (nmoves <= MCAP = NT: one move per thread; the
-            //      stack height and chunk count read once and kept in registers over the three steps) ----
-            const bool mine = tid < nmoves;
+            // ---- allocate new stack chunks, then write the entries (one move per thread; the stack height and chunk
+            //      count are read once and kept in registers) ----
             int32_t bk = 0, a_my = 0, c_my = 0, al_my = 0;
             if (mine) {
-                bk = G.bucket_base + (int32_t)(L.mkey[tid] >> 32);
-                a_my = A.bs_cnt[bk] + (tid - L.hidx[tid]);
+                bk = G.bucket_base + list_my;
+                a_my = A.bs_cnt[bk] + rank_my;
                 al_my = A.bs_alloc[bk];
                 c_my = bs_chunk_of(a_my);
                 if (c_my >= al_my && a_my == bs_chunk_start(c_my)) {
@@ -2275,18 +2384,15 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             const int32_t id0 = G.push_cnt;
             if (mine) {
                 int32_t sl = A.bs_dir[(int64_t)bk * BDIR + c_my] + (a_my - bs_chunk_start(c_my));
-                int32_t v = L.mval[tid];
-                A.bs_v[sl] = v; A.bs_id[sl] = id0 + tid;
-                A.pqpos[v] = id0 + tid;
-                const bool tail = (tid == nmoves - 1) || ((uint32_t)(L.mkey[tid + 1] >> 32) != (uint32_t)(L.mkey[tid] >> 32));
-                if (tail) {   // last move of its bucket group: the stack's new height (and chunk count)
+                A.bs_v[sl] = x_my; A.bs_id[sl] = id0 + pos_my;
+                A.pqpos[x_my] = id0 + pos_my;
+                if (tail_my) {   // last move of its bucket group: the stack's new height (and chunk count)
                     A.bs_cnt[bk] = a_my + 1;
                     if (c_my + 1 > al_my) A.bs_alloc[bk] = c_my + 1;
                 }
             }
             if (tid == 0) {
-                int32_t lst0 = (int32_t)(L.mkey[0] >> 32);
-                if (lst0 < G.minlist) G.minlist = lst0;
+                if ((int32_t)bmin < G.minlist) G.minlist = (int32_t)bmin;
                 G.push_cnt = id0 + nmoves;
             }
         }
