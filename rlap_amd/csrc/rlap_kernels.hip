@@ -2199,8 +2199,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 __syncthreads();
                 for (int w = 0; w < NWAVE; ++w) bmin = min(bmin, (uint32_t)L.scan[w]);
                 if (tid < P) L.hidx[tid] = incl - cnt_i + (tid >= 64 ? L.scan[NWAVE] : 0);
-                int32_t* const wtab = L.pslot;            // [NWAVE][64] move counts per (wave, bucket above the lowest); pslot is idle now
-                wtab[tid] = 0;
+                // [NWAVE][RB] move counts per (wave, bucket above the lowest); pslot is idle now (SLOTS = NWAVE * 256 ints)
+                constexpr int RB = 256, HCAP = 128;
+                static_assert(NWAVE * RB <= SLOTS && 2 * RB + 2 * HCAP <= 3 * CCAP * 2, "tables fit pslot / the record lists");
+                int32_t* const wtab = L.pslot;
+#pragma unroll
+                for (int k = 0; k < PASSES; ++k) wtab[k * NT + tid] = 0;
                 if (tid == 0) s_nhigh = 0;
                 __syncthreads();
                 uint32_t* const lst32 = reinterpret_cast<uint32_t*>(L.mkey);
@@ -2212,11 +2216,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 __syncthreads();
                 if (mine) { list_my = (int32_t)lst32[tid]; x_my = L.mval[tid]; }
                 const uint32_t brel = (uint32_t)list_my - bmin;
-                const bool low = mine && brel < 64u, high = mine && brel >= 64u;
-                int32_t* const btot = L.pslot + NT;       // [64] moves per low bucket
-                int32_t* const bstart = L.pslot + NT + 64;   // [64] first sorted position of a low bucket
-                int32_t* const hl_list = L.pslot + NT + 128; // [64] buckets of the moves beyond
-                int32_t* const hl_idx = L.pslot + NT + 192;  // [64] their places in (candidate, op) order
+                const bool low = mine && brel < (uint32_t)RB, high = mine && brel >= (uint32_t)RB;
+                int32_t* const btot = reinterpret_cast<int32_t*>(L.cont);     // [RB] moves per low bucket (the record lists are idle now)
+                int32_t* const bstart = btot + RB;                            // [RB] first sorted position of a low bucket
+                int32_t* const hl_list = bstart + RB;                         // [HCAP] buckets of the moves beyond
+                int32_t* const hl_idx = hl_list + HCAP;                       // [HCAP] their places in (candidate, op) order
                 int rank_w = 0;
                 {
                     const uint64_t lt = lanemask_lt(lane);
@@ -2226,27 +2230,35 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                         const uint32_t bb = (uint32_t)__shfl((int)brel, l);
                         const uint64_t same = __ballot(low && brel == bb);
                         if (low && brel == bb) rank_w = __popcll(same & lt);
-                        if (lane == l) wtab[(tid >> 6) * 64 + bb] = __popcll(same);
+                        if (lane == l) wtab[(tid >> 6) * RB + bb] = __popcll(same);
                         rem &= ~same;
                     }
                 }
-                if (high) { const int32_t q = atomicAdd(&s_nhigh, 1); if (q < 64) { hl_list[q] = list_my; hl_idx[q] = tid; } }
+                if (high) { const int32_t q = atomicAdd(&s_nhigh, 1); if (q < HCAP) { hl_list[q] = list_my; hl_idx[q] = tid; } }
                 __syncthreads();
                 const int32_t nhigh = s_nhigh;
-                fallback = nhigh > 64;
+                fallback = nhigh > HCAP;
                 if (!fallback) {
-                    if (tid < 64) {
+                    if (tid < RB) {   // per bucket: exclusive prefix over the waves, total
                         int acc = 0;
-                        for (int w = 0; w < NWAVE; ++w) { const int t = wtab[w * 64 + tid]; wtab[w * 64 + tid] = acc; acc += t; }
+                        for (int w = 0; w < NWAVE; ++w) { const int t = wtab[w * RB + tid]; wtab[w * RB + tid] = acc; acc += t; }
                         btot[tid] = acc;
-                        int inc2 = acc;
+                    }
+                    __syncthreads();
+                    if (tid < 64) {   // bucket starts: each lane of wave 0 takes RB/64 consecutive buckets
+                        int tsum = 0;
+#pragma unroll
+                        for (int u = 0; u < RB / 64; ++u) tsum += btot[tid * (RB / 64) + u];
+                        int inc2 = tsum;
                         for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc2, off); if (lane >= off) inc2 += t; }
-                        bstart[tid] = inc2 - acc;
+                        int run = inc2 - tsum;
+#pragma unroll
+                        for (int u = 0; u < RB / 64; ++u) { bstart[tid * (RB / 64) + u] = run; run += btot[tid * (RB / 64) + u]; }
                         if (tid == 63) s_nlow = inc2;
                     }
                     __syncthreads();
                     if (low) {
-                        rank_my = wtab[(tid >> 6) * 64 + brel] + rank_w;
+                        rank_my = wtab[(tid >> 6) * RB + brel] + rank_w;
                         pos_my = bstart[brel] + rank_my;
                         tail_my = rank_my == btot[brel] - 1;
                     } else if (high) {
