@@ -715,11 +715,11 @@ RLAP_HD void cand_meta(const Arrays& A, int32_t v, CT& C) {
     C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0; C.nkill = 0; C.nmv = 0;
     int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
     int32_t acnt = A.app_cnt[v];
+    int32_t base = A.app_chunk[v];              // read with the counts (not after them): one dependent round trip less
     C.cp1 = cp1; C.acnt = acnt; C.ext = (cp1 - cp0) + acnt;
     if (C.ext > CT::CAP) { C.flags = CF_BIG; C.ext = 0; return; }
     if (acnt > 0) {
         int ct = chunk_of(acnt - 1);            // <= 2 (CAP 32) / <= 3 (CAP 64) because acnt <= CAP
-        int32_t base = A.app_chunk[v];
         for (int c = ct; c >= 0; --c) { C.cb[c] = base; if (c > 0) base = A.e_nbr[base]; }
     }
 }
