@@ -171,7 +171,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     }
     st.nnz = nnz;
 
-    const int64_t pool = (int64_t)(h->pool_factor * nnz) + 16 * N + 1024;
+    // + what the workgroups may hold in reserve (one reservation each; the shape is chosen by graphs vs. CUs at launch)
+    const int64_t pool = (int64_t)(h->pool_factor * nnz) + 16 * N + 1024 + G * (G <= 512 ? (int64_t)POOL_GRAB_BIG : (int64_t)POOL_GRAB_SMALL);
     const int64_t slot_cap = (int64_t)nnz + pool;
     if (slot_cap >= ((int64_t)1 << 31) - 64) return RLAP_E_TOO_LARGE;
     ENSURE(h->e_nbr, 4 * slot_cap); ENSURE(h->e_val, 8 * slot_cap); ENSURE(h->e_twin, 4 * slot_cap);

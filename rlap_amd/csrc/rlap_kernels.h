@@ -11,6 +11,8 @@ enum { FLAG_RANGE = 0, FLAG_CROSS = 1, FLAG_COUNT = 4 };
 constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
 constexpr int SCAP = 512;  // output pass: same
 constexpr int BIGCAP = 8192;  // output pass, long columns: one workgroup with a 128 KB LDS record array
+constexpr int POOL_GRAB_BIG = 16384;   // append slots a 1024-thread workgroup reserves at a time (256-thread: POOL_GRAB_SMALL)
+constexpr int POOL_GRAB_SMALL = 2048;
 constexpr int HUGECAP = 65535; // output pass, longer still: records in global scratch (uint16 stop lists)
 
 // Global scratch for columns too long for LDS (sequential fallback).

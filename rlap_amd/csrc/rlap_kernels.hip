@@ -1406,13 +1406,14 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     A.o_n = ON;
     __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
-    __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow;
+    __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end;
+    constexpr int32_t POOL_GRAB = NT >= 1024 ? POOL_GRAB_BIG : POOL_GRAB_SMALL;   // slots reserved at a time for the round's appends
     __shared__ uint8_t s_eqperm[BC - 16][BC];   // std::sort's permutation of n = 17..BC all-equal keys
     __shared__ uint8_t s_eqinv[BC - 16][BC];    // its inverse: final position of the entry with id-rank r
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
-    if (tid == 0) { G = gd[g]; s_status = 0; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; }
+    if (tid == 0) { G = gd[g]; s_status = 0; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0; }
     for (int base = 0; base < BC - 16; base += BATCH) {   // the candidate records serve as scratch: BATCH lengths at a time
         const int row = base + tid;
         if (tid < BATCH && row < BC - 16) {
@@ -2074,10 +2075,17 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             int ntot;
             int nex = block_excl_scan<NWAVE>(need_thread, L.scan, &ntot);
             if (tid == 0) {
+                // slots come from a reservation this workgroup holds (refilled with one global atomic when it
+                // runs out): the round does not wait for a device-wide atomic
                 int32_t base = 0;
                 if (ntot > 0) {
-                    base = atomicAdd(A.pool_top, ntot);
-                    if (base < 0 || base > A.slot_cap - ntot) base = -1;
+                    if (s_pool_cur + ntot > s_pool_end) {
+                        const int32_t grab = ntot > POOL_GRAB ? ntot : POOL_GRAB;
+                        const int32_t b0 = atomicAdd(A.pool_top, grab);
+                        if (b0 < 0 || b0 > A.slot_cap - grab) { s_pool_cur = 0; s_pool_end = 0; base = -1; }
+                        else { s_pool_cur = b0; s_pool_end = b0 + grab; }
+                    }
+                    if (base == 0) { base = s_pool_cur; s_pool_cur += ntot; }
                 }
                 L.scan[NWAVE + 1] = base;
             }
