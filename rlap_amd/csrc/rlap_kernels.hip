@@ -2043,6 +2043,15 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             const CRec me = L.csorted[tid];
             chead = (tid == 0 || L.csorted[tid - 1].x != me.x) && me.i < P;
             if (chead) { ca0 = A.app_cnt[me.x]; cchunk0 = A.app_chunk[me.x]; }
+            // which positions of candidate me.i push into this target: found here by every record's own thread, so that
+            // the group walk below only steps through the set bits (the unsorted record list is free: used as scratch)
+            uint64_t pm = 0ull;
+            if (me.i < P) {
+                const Cand& C = L.cand[me.i];
+                if (A.o_v == OV_COARSEN) { if (me.j == C.koff) pm = ((C.m >= 64 ? ~0ull : ((1ull << C.m) - 1ull)) & ~(1ull << C.koff)); }
+                else for (int32_t p = 0; p < C.m - 1; ++p) pm |= (C.ksel[p] == me.j) ? (1ull << p) : 0ull;
+            }
+            L.cont[tid].x = (int32_t)(uint32_t)pm; L.cont[tid].j = (int32_t)(uint32_t)(pm >> 32);
         }
         // targets touched by one candidate only: one thread per (candidate, target); two passes so that
         // all loads are in flight together and the pool is bumped once per round
@@ -2143,7 +2152,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 int32_t key_final = 0, mvseq = -1;
                 for (int32_t r = q; r < ncont && csorted[r].x == x && csorted[r].i < P; ++r) {
                     Cand& C = L.cand[csorted[r].i];
-                    slots_into_target(A, C, csorted[r].j, a, chunk, &status, &L.pslot[csorted[r].i * BCAP]);
+                    uint64_t pm = ((uint64_t)(uint32_t)L.cont[r].j << 32) | (uint32_t)L.cont[r].x;
+                    int32_t* pslot_row = &L.pslot[csorted[r].i * BCAP];
+                    while (pm && status == 0) { const int p = __builtin_ctzll(pm); pm &= pm - 1; pslot_row[p] = alloc_in_column(A, a, chunk, &status); }
                     TRes R = ent_tres(C.e[csorted[r].j]);
                     key_final = R.key_after;
                     if (R.mv >= 0) mvseq = (csorted[r].i << 8) | R.mv;
