@@ -1606,21 +1606,28 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                         if (live) rk[k] = __popcll(half & ~((2ull << e) - 1ull));
                         if (e == 0) C.m = __popcll(half);
                     } else if (!MERGE) {
-                        if (live) {
-                            const int32_t ext = C.ext, me = ln[k];
-                            int32_t r = 0, nlive = 0;
-                            bool dup = false;
-                            for (int32_t q = 0; q < ext; ++q) {
-                                bool lq = C.e[q].val > 0;
-                                int32_t nq = C.e[q].nbr;
-                                nlive += lq ? 1 : 0;
-                                r += (lq && nq < me) ? 1 : 0;
-                                dup |= (lq && nq == me && q != e);
+                        // columns with appended entries (or an unsorted CSR segment): rank by id with a bitonic network over the
+                        // half-wave's registers -- (id, lane) pairs, dead entries last; equal ids = multi-edge -> single-vertex path
+                        uint32_t skey = live ? (uint32_t)ln[k] : 0x7FFFFFFFu;
+                        int ssrc = e;
+#pragma unroll
+                        for (int kk = 2; kk <= BC; kk <<= 1) {
+#pragma unroll
+                            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                                const uint32_t okey = (uint32_t)__shfl_xor((int)skey, jj);
+                                const int osrc = __shfl_xor(ssrc, jj);
+                                const bool keep_min = (((e & jj) == 0) == ((e & kk) == 0));
+                                const bool other_less = okey < skey || (okey == skey && osrc < ssrc);
+                                if (keep_min == other_less) { skey = okey; ssrc = osrc; }
                             }
-                            rk[k] = r;
-                            if (dup) atomicOr(&C.flags, CF_DUP);
-                            if (r == 0) C.m = nlive;
                         }
+                        // lane p now holds the p-th pair: tell the source lane its rank (forward permute), look for equal neighbours
+                        const uint32_t pkey = (uint32_t)__shfl_up((int)skey, 1);
+                        const bool dupp = e > 0 && skey == pkey && skey != 0x7FFFFFFFu;
+                        const int myrank = __builtin_amdgcn_ds_permute(((lane & GSH) + ssrc) << 2, e);
+                        if (__ballot(dupp) >> (lane & GSH) & GMASK) { if (e == 0) atomicOr(&C.flags, CF_DUP); }
+                        if (live) rk[k] = myrank;
+                        if (e == 0) C.m = __popcll(half);
                     } else {
                         // one wave = this candidate.  Multi-edges are merged here (no PQ to replay in this mode): the
                         // position std::sort by id gives every live entry (stable rank up to 16 entries, the
