@@ -1850,24 +1850,28 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         if (tid < BATCH) L.cmask[tid] = 0ull;
         // ================= P1b: first candidate that depends on an earlier one =================
         if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);
-        #pragma unroll 1
-        for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
+        // the look-ups are issued, then the RNG offsets' scan (P2) runs while they are in flight: a prefix sum does not
+        // depend on what follows it, so it is taken over all candidates of the round before the cut is known
+        int32_t bpk[PASSES];
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
             const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
-            const bool act = (i < nc) && (j < L.cand[i].m);
-            if (__ballot(act) == 0ull) continue;
-            if (act) {
-                int32_t bp = batch_pos[L.cand[i].e[j].nbr];
-                if (bp >= 0 && bp < i) atomicMin(&s_pmax, i);
-            }
+            bpk[k] = -1;
+            if ((i < nc) && (j < L.cand[i].m)) bpk[k] = batch_pos[L.cand[i].e[j].nbr];
+        }
+        int dtot;
+        const int dex = block_excl_scan<NWAVE>((tid < nc && !first_is_big) ? L.cand[tid].ndraw : 0, L.scan, &dtot);
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
+            const int32_t i = tid / (NT / BATCH);
+            if (bpk[k] >= 0 && bpk[k] < i) atomicMin(&s_pmax, i);
         }
         __syncthreads();
         const int32_t Pmax = first_is_big ? 0 : (s_pmax < nc ? s_pmax : nc);
         int32_t P = 0;
         PHASE_STAMP(2);
         if (Pmax > 0) {
-            // ================= P2: RNG offsets =================
-            int dtot;
-            int dex = block_excl_scan<NWAVE>(tid < Pmax ? L.cand[tid].ndraw : 0, L.scan, &dtot);
+            // (dtot covers the whole round: at most 4k uniforms more than the prefix needs; the table has that slack)
             if (G.n_draws + dtot > A.rng_len) { if (tid == 0) s_status = ST_RNG_OVERFLOW; __syncthreads(); break; }
             // ================= P3: sampling =================
             if (tid < Pmax) {
