@@ -52,7 +52,7 @@ struct rlap_handle_s {
     DevBuf node_ptr_d, vgraph, flags, acc, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, gcol;
     // graph state
     DevBuf e_nbr, e_val, e_twin, app_cnt, app_chunk, key, pqpos, ocur, oend, origpos, orig_order, gd_d, pool_top;
-    DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, tcount, prof;
+    DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, prof;
     DevBuf skey0, skey1, sval0, sval1;
     DevBuf rng;
     int64_t rng_len = 0;
@@ -229,13 +229,12 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     ENSURE(h->ocur, 4 * bucket_total); ENSURE(h->oend, 4 * bucket_total);
     ENSURE(h->bs_cnt, 4 * bucket_total); ENSURE(h->bs_alloc, 4 * bucket_total); ENSURE(h->bs_dir, 4 * bucket_total * BDIR);
     ENSURE(h->bs_v, 4 * log_total); ENSURE(h->bs_id, 4 * log_total); ENSURE(h->bs_pool_top, 4);
-    ENSURE(h->batch_pos, 4 * N); ENSURE(h->tcount, 4 * N);
+    ENSURE(h->batch_pos, 4 * N);
     ENSURE(h->skey0, 8 * N); ENSURE(h->skey1, 8 * N); ENSURE(h->sval0, 4 * N); ENSURE(h->sval1, 4 * N);
     HIPCHK(hipMemsetAsync(h->bs_cnt.p, 0, 4 * bucket_total, s));
     HIPCHK(hipMemsetAsync(h->bs_alloc.p, 0, 4 * bucket_total, s));
     HIPCHK(hipMemsetAsync(h->bs_pool_top.p, 0, 4, s));
     HIPCHK(hipMemsetAsync(h->batch_pos.p, 0xFF, 4 * N, s));
-    HIPCHK(hipMemsetAsync(h->tcount.p, 0, 4 * N, s));
     HIPCHK(hipMemsetAsync(h->ocur.p, 0, 4 * bucket_total, s));
     HIPCHK(hipMemsetAsync(h->oend.p, 0, 4 * bucket_total, s));
     hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->vgraph.as<int32_t>(), (int32_t)N, h->key.as<int32_t>(),
@@ -280,7 +279,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
 
     if (h->timing) HIPCHK(hipEventRecord(h->ev[1], s));
     // ---------------- elimination ----------------
-    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>(), h->tcount.as<int32_t>());
+    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>());
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
     HIPCHK(hipMemcpyAsync(gd.data(), h->gd_d.p, sizeof(GraphDesc) * G, hipMemcpyDeviceToHost, s));
@@ -429,7 +428,7 @@ int rlap_destroy(rlap_handle h) {
     if (!h) return RLAP_OK;
     DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->flags, &h->acc, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
                       &h->deg, &h->colptr, &h->slot_col, &h->gcol, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
-                      &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->tcount, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
+                      &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
                       &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters, &h->biglist, &h->biglists, &h->hugelists};
     for (DevBuf* b : bufs) b->release();

@@ -67,7 +67,7 @@ __global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t 
 __global__ void k_bucket_bounds(const uint32_t* order, const int32_t* key, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
                                 int32_t* ocur, int32_t* oend, int32_t* origpos);
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
-                            int32_t* batch_pos, int32_t* tcount);
+                            int32_t* batch_pos);
 __global__ void k_sc_keys(const int32_t* key, const int32_t* pqpos, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,
                           int32_t N, uint64_t* skey, uint32_t* sval);
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,

@@ -1384,7 +1384,7 @@ __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G
 // per round by every wave) small enough for the instruction cache.
 template <int OV, int ON, int BC, int NTT>
 __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
-                                                           int32_t* __restrict__ batch_pos, int32_t* __restrict__ tcount) {
+                                                           int32_t* __restrict__ batch_pos) {
     constexpr int NT = NTT;            // threads per workgroup
     constexpr int NWAVE = NT / 64;
     constexpr int SLOTS = PASSES * NT; // candidates x slots per round
@@ -1392,7 +1392,6 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     constexpr int CCAP = NT / 2;       // contended records per round
     constexpr int HBITS = (SLOTS == 4096) ? 12 : (SLOTS == 2048) ? 11 : 10;   // log2(SLOTS): size of the target hash table
     static_assert((1 << HBITS) == SLOTS, "hash table = one place per slot");
-    (void)tcount;
     // BC slots per candidate: a group of BC lanes (half a wave or a whole wave) works on one candidate
     constexpr int BCAP = BC;
     constexpr int BATCH = SLOTS / BC;
@@ -2459,7 +2458,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
 }
 
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
-                            int32_t* batch_pos, int32_t* tcount) {
+                            int32_t* batch_pos) {
     // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
     // turn comes): it runs with 64 slots per candidate (64 candidates per round); the min-degree orders with 32.
     // more graphs than CUs: the 256-thread shape, three workgroups per CU (measured on 4096-node graphs: the same
@@ -2469,8 +2468,8 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, co
     bool many = G > (unsigned)n_cu;
     if (const char* e = std::getenv("RLAP_BATCH_SHAPE")) { if (e[0] == '2') many = true; else if (e[0] == '1') many = false; }   // diagnostic override: 256 / 1024
 #define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { \
-        if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos, tcount); \
-        else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, tcount); \
+        if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos); \
+        else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos); \
         return; }
     RLAP_CASE(OV_RANDOM, ON_ASC, 64) RLAP_CASE(OV_RANDOM, ON_DESC, 64) RLAP_CASE(OV_RANDOM, ON_RANDOM, 64)
     RLAP_CASE(OV_DEGREE, ON_ASC, 32) RLAP_CASE(OV_DEGREE, ON_DESC, 32) RLAP_CASE(OV_DEGREE, ON_RANDOM, 32)
