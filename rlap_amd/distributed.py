@@ -28,12 +28,23 @@ def all_gather_rows(local: torch.Tensor, group=None) -> Tuple[torch.Tensor, torc
     counts = torch.cat(counts)
     mx = int(counts.max().item())
     C = local.shape[1]
-    pad = torch.zeros((mx, C), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    out = torch.cat([bufs[r][: int(counts[r])] for r in range(world)], dim=0)
-    return out, counts.cpu()
+    if local.shape[0] == mx:
+        pad = local.contiguous()
+    else:
+        pad = torch.empty((mx, C), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+        pad[local.shape[0]:] = 0
+    big = torch.empty((world * mx, C), dtype=local.dtype, device=local.device)
+    try:
+        dist.all_gather_into_tensor(big, pad, group=group)     # one flat receive buffer (RCCL: a single ring all-gather)
+    except (RuntimeError, NotImplementedError, AttributeError):
+        bufs = list(big.view(world, mx, C).unbind(0))
+        dist.all_gather(bufs, pad, group=group)
+    counts_h = counts.cpu()
+    if bool((counts_h == mx).all()):
+        return big, counts_h
+    out = torch.cat([big[r * mx: r * mx + int(counts_h[r])] for r in range(world)], dim=0)
+    return out, counts_h
 
 
 def sharded_approximate_cholesky(
