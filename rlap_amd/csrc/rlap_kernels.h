@@ -77,7 +77,6 @@ void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, c
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
                      unsigned long long* live_total, int32_t* lists, int32_t* counts);
 __global__ void k_debug_wave_sort(const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out);
-__global__ void k_sc_biglist(const int32_t* ext, int32_t S, int32_t keyed, int32_t* list, int32_t* count);
 __global__ void k_sc_merge_big(Arrays A, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
                                int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists);
 __global__ void k_sc_merge_huge(Arrays A, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,

@@ -5,9 +5,13 @@
 //   K2+K3 k_twin_sym         symmetry check + twin index (factorizers.cc:19-22,
 //                            preconditioner.cc:22-49)
 //   K4  k_pq_init/k_bucket_bounds  bucket queue (preconditioner.cc:125-165)
-//   K5-K8 k_eliminate        one wave per graph, exact sequential semantics
+//   K5-K8 k_eliminate_batch_t<o_v,o_n,slots,threads>  one workgroup per graph, rounds of independent
+//                            vertices with exact sequential semantics; wave_eliminate / wave_eliminate_big /
+//                            serial_eliminate for what a round cannot take
 //                            (preconditioner.cc:348-433 | 713-787 | 835-914)
-//   K9  k_sc_keys/k_sc_ext/k_sc_merge/k_sc_compact  output (:435-457,312-345)
+//   K9  k_sc_keys/k_sc_ext/k_sc_tierlists/k_sc_merge_t<cap>/k_sc_merge_big/k_sc_merge_huge/k_sc_compact
+//                            output (:435-457,312-345)
+//   wave_std_sort / wave_sort64 / group_sort   libstdc++ std::sort's permutation, in parallel
 //
 // Compiled with -ffp-contract=off: the reference is built without FMA
 // (setup.py:26-37), and index selection depends on the exact roundings.
@@ -2797,19 +2801,12 @@ void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, c
 }
 
 // Long columns (SCAP < extent <= BIGCAP): one single-wave workgroup per column with the whole
-// column in LDS as 16-byte records {id as double, weight}; both sorts are the std::sort emulation
-// run by one lane on LDS (exact under ties), gather / merge bookkeeping / stores by the wave.
+// column in LDS as 16-byte records {id as double, weight}; both sorts are the wave-parallel std::sort
+// restatement (exact under ties), gather / merge / stores by the wave.
 struct Rec2 { double a; double b; };
 struct Rec2LessA { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.a < y.a; } };
 struct Rec2LessB { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.b < y.b; } };
 struct Rec2GreaterB { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.b > y.b; } };
-
-__global__ void k_sc_biglist(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ list, int32_t* __restrict__ count) {
-    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= S || keyed) return;
-    int32_t e = ext[i];
-    if (e > SCAP && e <= BIGCAP) list[atomicAdd(count, 1)] = i;
-}
 
 // HUGE = false: SCAP < extent <= BIGCAP, records in LDS.  HUGE = true: BIGCAP < extent <= HUGECAP (a hub of a
 // weighted graph), records in global scratch (L2), both sorts by the wave-parallel restatement.
