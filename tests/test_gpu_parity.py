@@ -187,6 +187,34 @@ def test_long_surviving_columns(ops, o_n):
                 assert_same(b, a, f"star{n} t={t} {o_n} {'unit' if w is None else 'weighted'}")
 
 
+def test_many_far_bucket_moves(ops):
+    """PQ move order: a round whose moves spread over more than 256 buckets above the lowest, with hundreds of
+    them beyond (hubs of degree >= 400 next to vertices of degree ~25) -- the counting placement's second class
+    and its bitonic fall-back.  Leaves (degree 10) are eliminated 128 a round; every one touches 5 hubs and 5 mids."""
+    rs = np.random.RandomState(5)
+    n_leaf, n_mid, n_hub = 3000, 600, 400
+    n = n_leaf + n_mid + n_hub
+    hub0, mid0 = n_leaf + n_mid, n_leaf
+    src, dst = [], []
+    for a in range(n_hub):
+        for b in range(a + 1, n_hub):
+            src.append(hub0 + a); dst.append(hub0 + b)
+    for v in range(n_leaf):
+        for h in rs.choice(n_hub, 5, replace=False):
+            src.append(v); dst.append(hub0 + int(h))
+        for q in rs.choice(n_mid, 5, replace=False):
+            src.append(v); dst.append(mid0 + int(q))
+    src = np.array(src); dst = np.array(dst)
+    ei = np.stack([np.concatenate([src, dst]), np.concatenate([dst, src])]).astype(np.int64)
+    order = np.lexsort((ei[0], ei[1]))
+    ei = ei[:, order]
+    for o_n in ("asc", "desc"):
+        for w in (None, sym_weights(ei, n, 4)):
+            a = oracle.approximate_cholesky(ei, w, n, 2500, "degree", o_n, shuffle_seed=2)
+            b = gpu_call(ops, ei, w, n, 2500, "degree", o_n, seed=2)
+            assert_same(b, a, f"far buckets {o_n} {'unit' if w is None else 'weighted'}")
+
+
 def test_reference_unit_test_shape(ops):
     # reference tests/test_rlap.py:39-61: BA(100, 50), ones((1,E)) weights, t=50, random/asc
     n = 100
