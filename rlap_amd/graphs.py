@@ -27,3 +27,16 @@ def batch_disjoint(edge_indices, num_nodes):
         parts.append(ei + ptr[-1])
         ptr.append(ptr[-1] + int(n))
     return torch.cat(parts, dim=1), torch.tensor(ptr, dtype=torch.int64)
+
+
+def to_undirected(edge_index: torch.Tensor, num_nodes: int = None) -> torch.Tensor:
+    """Device-side stand-in for the step the reference's scripts run before the op (PyG `to_undirected`,
+    scripts/node_shared.py:326-327, tests/test_rlap.py:31): add the reverse of every edge and drop duplicates.
+    Runs where `edge_index` lives (one sort of 64-bit keys); returns edges sorted by (row, col).  Pass `num_nodes`
+    to avoid the host sync of `edge_index.max()`."""
+    if edge_index.numel() == 0:
+        return edge_index
+    n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
+    both = torch.cat([edge_index, edge_index.flip(0)], dim=1).to(torch.int64)
+    key = torch.unique(both[0] * n + both[1])          # sorted, duplicates removed
+    return torch.stack([torch.div(key, n, rounding_mode="floor"), key % n])

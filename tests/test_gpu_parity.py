@@ -356,6 +356,24 @@ def test_device_native_adapters(ops):
     assert nn == n and np.array_equal(ei2.cpu().numpy(), ref[:, :2].astype(np.int64).T)
 
 
+def test_to_undirected_on_device_feeds_the_op(ops):
+    # the step before the path: one-directional edges -> symmetric, coalesced, on the device
+    from rlap_amd import graphs
+    rs = np.random.RandomState(0)
+    n = 500
+    src = rs.randint(0, n, 3000); dst = rs.randint(0, n, 3000)
+    keep = src != dst
+    ei = torch.from_numpy(np.stack([src[keep], dst[keep]])).cuda()
+    und = graphs.to_undirected(ei, n)
+    assert und.is_cuda
+    a = und.cpu().numpy()
+    fw = set(map(tuple, a.T))
+    assert all((c, r) in fw for r, c in fw) and len(fw) == a.shape[1]
+    got = ops.approximate_cholesky(und, None, n, n // 2, "degree", "asc").numpy()
+    ref = oracle.approximate_cholesky(a, None, n, n // 2, "degree", "asc")
+    assert_same(got, ref, "to_undirected -> approximate_cholesky")
+
+
 def test_ppr_diffusion_adapter(ops):
     # the only caller that uses the output WEIGHTS (augmentor_benchmarks.py:121-171)
     from rlap_amd.adapters import rLapPPRDiffusion, compute_ppr
