@@ -215,6 +215,46 @@ def test_many_far_bucket_moves(ops):
             assert_same(b, a, f"far buckets {o_n} {'unit' if w is None else 'weighted'}")
 
 
+def _random_graph(rs, n, p, dense_hub):
+    src, dst = np.nonzero(np.triu(rs.rand(n, n) < p, 1))
+    if dense_hub and n > 3:   # one vertex adjacent to almost everything: long columns, shared targets
+        h = int(rs.randint(n))
+        others = np.array([v for v in range(n) if v != h and rs.rand() < 0.9], dtype=np.int64)
+        src = np.concatenate([src, np.full(others.shape[0], h)]); dst = np.concatenate([dst, others])
+    a = np.minimum(src, dst); b = np.maximum(src, dst)
+    key = np.unique(a * n + b)
+    a, b = key // n, key % n
+    ei = np.stack([np.concatenate([a, b]), np.concatenate([b, a])]).astype(np.int64)
+    return ei[:, np.lexsort((ei[0], ei[1]))]
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_fuzz_small_graphs_against_oracle(ops, block):
+    """Seeded random graphs (sparse to dense, with and without a hub), random mode, num_remove, unit / tie-heavy /
+    tie-free weights: every result bit-exact against the oracle."""
+    rs = np.random.RandomState(1000 + block)
+    for trial in range(40):
+        n = int(rs.choice([1, 2, 3, 5, 8, 17, 33, 40, 65, 90, 130, 200]))
+        p = float(rs.choice([0.0, 0.02, 0.1, 0.3, 0.7, 1.0]))
+        ei = _random_graph(rs, n, p, dense_hub=bool(rs.rand() < 0.3))
+        o_v = str(rs.choice(["degree", "random", "coarsen"]))
+        o_n = str(rs.choice(["asc", "desc", "random"]))
+        t = int(rs.choice([0, 1, n // 3, n // 2, max(n - 1, 0), n + 3]))
+        wkind = int(rs.randint(3))
+        if wkind == 0 or ei.shape[1] == 0:
+            w = None
+        elif wkind == 1:   # few distinct values: ties everywhere, but not all equal
+            w = sym_weights(ei, n, int(rs.randint(1 << 30)))
+            w = np.round(w * 2) / 2 + 0.5
+        else:
+            w = sym_weights(ei, n, int(rs.randint(1 << 30)))
+        perm = rs.permutation(n) if o_v == "random" else None
+        seed = int(rs.randint(1 << 30))
+        a = oracle.approximate_cholesky(ei, w, n, t, o_v, o_n, perm=perm, shuffle_seed=seed)
+        b = gpu_call(ops, ei, w, n, t, o_v, o_n, perm=perm, seed=seed)
+        assert_same(b, a, f"block {block} trial {trial}: n={n} p={p} {o_v}/{o_n} t={t} w={wkind}")
+
+
 def test_reference_unit_test_shape(ops):
     # reference tests/test_rlap.py:39-61: BA(100, 50), ones((1,E)) weights, t=50, random/asc
     n = 100
