@@ -340,8 +340,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = bigcap; SS.top = counters + 0;
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
     if (S > 0) {
-        ENSURE(h->biglist, 4 * 5 * (S + 1));
-        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 5 ints: tiers 0..4
+        ENSURE(h->biglist, 4 * 6 * (S + 1));
+        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 6 ints: tiers 0..5
         launch_sc_merge(s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
                         h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1, h->biglist.as<int32_t>(), tiercounts);
         HIPCHK(hipGetLastError());

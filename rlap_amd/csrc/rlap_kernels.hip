@@ -2764,19 +2764,20 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
     }
 }
 
-// work lists per capacity tier (0: <=64, 1: <=192, 2: <=512 and what the long-column kernels do not take, 3: k_sc_merge_big, 4: k_sc_merge_huge)
+// work lists per capacity tier (5: <=32 (two columns per wave), 0: <=64, 1: <=192, 2: <=512 and what the long-column kernels
+// do not take, 3: k_sc_merge_big, 4: k_sc_merge_huge)
 __global__ __launch_bounds__(256) void k_sc_tierlists(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tier = -1;
     if (i < S) {
         int32_t e = ext[i];
-        tier = e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && !keyed && e <= HUGECAP) ? (e <= BIGCAP ? 3 : 4) : 2));
+        tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && !keyed && e <= HUGECAP) ? (e <= BIGCAP ? 3 : 4) : 2));
     }
     // one atomic per wave and tier: neighbouring columns stay neighbours in the list (locality of the
     // staged rows), while the waves' chunks interleave (balance)
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < 6; ++t) {
         uint64_t mk = __ballot(tier == t);
         if (mk == 0ull) continue;
         int32_t base = 0;
@@ -2787,11 +2788,128 @@ __global__ __launch_bounds__(256) void k_sc_tierlists(const int32_t* __restrict_
     }
 }
 
+// Columns of at most 32 slots (most of them after half the vertices are gone): TWO per wave, one per half-wave, entirely
+// in registers -- the column is read one slot per lane, compacted, ordered by id and by o_n with group_sort<32> (the
+// std::sort restatement for two 32-lane groups), merged with shuffles, and stored from the lanes.  A column whose sort
+// hits the depth limit is handed to the 64-entry kernel's list.
+__global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const uint32_t* __restrict__ order, const int64_t* __restrict__ tmp_off,
+                                                      int32_t* __restrict__ tmp_nbr, double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
+                                                      unsigned long long* __restrict__ live_total, const int32_t* __restrict__ worklist,
+                                                      const int32_t* __restrict__ workcount, int32_t* __restrict__ list64, int32_t* __restrict__ count64) {
+    __shared__ int32_t s_tmp[2 * (2 * 34 + 12)];
+    const int lane = lane_id();
+    const int gl = lane & 31, gbase = lane & 32;
+    const uint64_t gmask = 0xFFFFFFFFull << gbase;
+    const uint64_t lt = lanemask_lt(lane) & gmask;
+    const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
+    const bool desc = (A.o_n == ON_DESC) && !keyed;
+    const int32_t nwork = *workcount;
+    auto to_lane = [&](int target, int v) { return __builtin_amdgcn_ds_permute((gbase + target) << 2, v); };   // forward permute inside the half
+    auto to_lane_d = [&](int target, double v) {
+        const long long b = __double_as_longlong(v);
+        const int lo = to_lane(target, (int)(uint32_t)b), hi = to_lane(target, (int)(uint32_t)((unsigned long long)b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+    };
+    for (int32_t w0 = 2 * blockIdx.x; w0 < nwork; w0 += 2 * gridDim.x) {
+        const int32_t wi = w0 + (lane >> 5);
+        const bool have = wi < nwork;
+        int32_t i = 0, v = 0, cp1 = 0, acnt = 0, ext = 0, cb0 = 0, cb1 = 0, cb2 = 0;
+        int64_t toff = 0;
+        if (have) {
+            i = worklist[wi];
+            v = (int32_t)order[i];
+            toff = tmp_off[i];
+            const int32_t cp0 = A.colptr[v];
+            cp1 = A.colptr[v + 1];
+            acnt = A.app_cnt[v];
+            ext = (cp1 - cp0) + acnt;
+            if (acnt > 0) {   // bases of the (at most three) appended chunks
+                const int ct = chunk_of(acnt - 1);
+                int32_t base = A.app_chunk[v];
+                if (ct == 2) { cb2 = base; base = A.e_nbr[base]; }
+                if (ct >= 1) { cb1 = base; base = A.e_nbr[base]; }
+                cb0 = base;
+            }
+        }
+        // one slot per lane, in the traversal order of :248-271 (appended entries newest first, then the CSR segment backwards)
+        double val = 0; int32_t nb = 0;
+        if (gl < ext) {
+            int32_t sl;
+            if (gl < acnt) { const int32_t a = acnt - 1 - gl; const int c = chunk_of(a); sl = (c == 0 ? cb0 : c == 1 ? cb1 : cb2) + 1 + (a - chunk_start(c)); }
+            else sl = cp1 - 1 - (gl - acnt);
+            val = A.e_val[sl]; nb = A.e_nbr[sl];
+        }
+        const bool live = gl < ext && val > 0;
+        const uint64_t lm = __ballot(live) & gmask;
+        const int nlive = __popcll(lm);
+        // compact the live entries to the front of the half (a permutation: dead lanes go behind)
+        {
+            const int below = __popcll(lm & lt);
+            const int target = live ? below : nlive + (gl - below);
+            nb = to_lane(target, nb);
+            val = to_lane_d(target, val);
+        }
+        // order by id (:314-315)
+        bool ok = true;
+        {
+            double key = (double)nb; int idx = gl, pos = gl;
+            const bool want = have && nlive > 1;
+            const bool okg = group_sort<false, 32>(key, idx, nlive, want, lane, s_tmp, &pos);
+            if (want) {
+                ok = okg;
+                const double ve = __shfl(val, gbase + idx);
+                const int target = gl < nlive ? pos : gl;
+                nb = to_lane(target, (int32_t)key);
+                val = to_lane_d(target, ve);
+            }
+        }
+        // merge (:317-329): the first of a run of equal ids takes the sum, in sorted order
+        int m = nlive;
+        {
+            const int32_t nbp = __shfl_up(nb, 1);
+            const bool head = gl < nlive && (gl == 0 || nb != nbp);
+            const uint64_t hm = __ballot(head) & gmask;
+            m = __popcll(hm);
+            if (m != nlive) {   // (group-uniform)
+                double acc = val;
+                const uint64_t above = (gl == 31) ? 0ull : ((hm >> (lane + 1)) & (0xFFFFFFFFull >> (gl + 1)));
+                const int nexthead = above ? (gl + 1 + __builtin_ctzll(above)) : nlive;
+                for (int q = 1; q < 32; ++q) {   // shuffles must be executed by the whole half: fixed trip count, predicated adds
+                    const double vq = __shfl(val, gbase + ((gl + q) & 31));
+                    if (head && gl + q < nexthead) acc += vq;
+                }
+                const int below = __popcll(hm & lt);
+                const int target = head ? below : (gl < nlive ? m + (gl - below) : gl);
+                nb = to_lane(target, nb);
+                val = to_lane_d(target, acc);
+            }
+        }
+        // order by o_n (:331-343) and store from the lanes
+        {
+            double key = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, v, 1), nb) : val;
+            int idx = gl, pos = gl;
+            const bool want = have && m > 1;
+            const bool okg = desc ? group_sort<true, 32>(key, idx, m, want, lane, s_tmp, &pos) : group_sort<false, 32>(key, idx, m, want, lane, s_tmp, &pos);
+            if (want) ok = ok && okg;
+            const int32_t nbo = __shfl(nb, gbase + idx);
+            const double vo = __shfl(val, gbase + idx);
+            if (have && ok && gl < m) { tmp_nbr[toff + pos] = nbo; tmp_val[toff + pos] = vo; }
+        }
+        if (have && gl == 0) {
+            if (ok) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)nlive); }
+            else list64[atomicAdd(count64, 1)] = i;   // depth limit hit: the 64-entry kernel (launched after this one) takes it
+        }
+    }
+}
+
 void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
                      unsigned long long* live_total, int32_t* lists, int32_t* counts) {
     const int keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) ? 1 : 0;
     hipLaunchKernelGGL(k_sc_tierlists, dim3((S + 255) / 256), dim3(256), 0, stream, ext, S, keyed, lists, counts);
+    unsigned gh = (unsigned)(S < 256 * 32 * 4 ? (S + 1) / 2 : 256 * 32 * 4);
+    if (gh == 0) gh = 1;
+    hipLaunchKernelGGL(k_sc_merge_half, dim3(gh), dim3(64), 0, stream, A, order, tmp_off, tmp_nbr, tmp_val, cnt_out, live_total, lists + 5 * (size_t)S, counts + 5, lists, counts);
     unsigned g0 = (unsigned)(S < 256 * 32 * 4 ? S : 256 * 32 * 4);
     unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
     unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
