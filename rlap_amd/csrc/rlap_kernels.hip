@@ -2632,10 +2632,9 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
         const int64_t toff = tmp_off[i];
         const int32_t ex = ext[i];
         if (ex > SCAP) {
-            // long column: k_sc_merge_big takes it (LDS), unless it is too long for that or the order is keyed:
+            // long column: k_sc_merge_big / k_sc_merge_huge take it, unless it is too long even for their 16-bit stop lists:
             // then the sequential form in global scratch (one lane)
-            const bool keyed_order = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
-            if (lane == 0 && (keyed_order || ex > HUGECAP)) {
+            if (lane == 0 && ex > HUGECAP) {
                 unsigned long long off = atomicAdd(SS.top, (unsigned long long)ex);
                 ColBuf B = SS.colbuf((int64_t)off);
                 GraphDesc D = gd[vgraph[v]];
@@ -2770,9 +2769,10 @@ __global__ __launch_bounds__(256) void k_sc_tierlists(const int32_t* __restrict_
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tier = -1;
+    (void)keyed;
     if (i < S) {
         int32_t e = ext[i];
-        tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && !keyed && e <= HUGECAP) ? (e <= BIGCAP ? 3 : 4) : 2));
+        tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= HUGECAP) ? (e <= BIGCAP ? 3 : 4) : 2));
     }
     // one atomic per wave and tier: neighbouring columns stay neighbours in the list (locality of the
     // staged rows), while the waves' chunks interleave (balance)
@@ -2925,6 +2925,11 @@ struct Rec2 { double a; double b; };
 struct Rec2LessA { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.a < y.a; } };
 struct Rec2LessB { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.b < y.b; } };
 struct Rec2GreaterB { __device__ bool operator()(const Rec2& x, const Rec2& y) const { return x.b > y.b; } };
+// keyed neighbour order (o_n = random / coarsen): the key is a hash of the neighbour id, recomputed per comparison
+struct Rec2LessKeyed {
+    uint64_t kb;
+    __device__ bool operator()(const Rec2& x, const Rec2& y) const { return keyed_order_dkey(kb, (int32_t)x.a) < keyed_order_dkey(kb, (int32_t)y.a); }
+};
 
 // HUGE = false: SCAP < extent <= BIGCAP, records in LDS.  HUGE = true: BIGCAP < extent <= HUGECAP (a hub of a
 // weighted graph), records in global scratch (L2), both sorts by the wave-parallel restatement.
@@ -3011,7 +3016,9 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const uint32
             __syncthreads();
             m += popc64(mask);
         }
-        if (A.o_n == ON_ASC) wave_std_sort<Rec2>(R, m, Rec2LessB(), WP, lane); else wave_std_sort<Rec2>(R, m, Rec2GreaterB(), WP, lane);   // :331-338
+        if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) { Rec2LessKeyed lk; lk.kb = keyed_order_base(A.shuffle_seed, v, 1); wave_std_sort<Rec2>(R, m, lk, WP, lane); }   // :339-343
+        else if (A.o_n == ON_ASC) wave_std_sort<Rec2>(R, m, Rec2LessB(), WP, lane);
+        else wave_std_sort<Rec2>(R, m, Rec2GreaterB(), WP, lane);   // :331-338
         __syncthreads();
         for (int32_t j = lane; j < m; j += 64) { tmp_nbr[toff + j] = (int32_t)R[j].a; tmp_val[toff + j] = R[j].b; }
         if (lane == 0) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)len0); }
