@@ -1896,12 +1896,15 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             __syncthreads();
             PHASE_STAMP(3);
             // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
-            #pragma unroll 1
-            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
+            int32_t key0k[PASSES];   // the targets' keys: fetched here, used after the barrier (their latency hides behind the table)
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                key0k[k] = 1;
                 if (i >= Pmax) continue;
                 if (j < L.cand[i].m) {
                     const int32_t x = L.cand[i].e[j].nbr;
+                    if (use_pq) key0k[k] = A.key[x];
                     uint32_t hh = ((uint32_t)x * 2654435761u) >> (32 - HBITS);
                     while (true) {   // linear probing; at most SLOTS distinct keys in SLOTS places
                         const int32_t cur = hkeys[hh];
@@ -1913,8 +1916,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 }
             }
             __syncthreads();
-            #pragma unroll 1
-            for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
                 if (i >= Pmax) continue;
                 Cand& C = L.cand[i];
@@ -1923,7 +1926,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 uint32_t hh = ((uint32_t)x * 2654435761u) >> (32 - HBITS);
                 while (hkeys[hh] != x) hh = (hh + 1) & (SLOTS - 1);
                 const int32_t tc = hcnt[hh];
-                const int32_t key0 = use_pq ? A.key[x] : 1;
+                const int32_t key0 = key0k[k];
                 TRes& R = ent_tres(C.e[j]);
                 if (tc > 1) {
                     // the key-independent half of the replay now, in parallel; the walk below chains the keys
