@@ -1534,6 +1534,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     lv[k] = A.e_val[sl]; ln[k] = A.e_nbr[sl]; lt[k] = A.e_twin[sl];
                 }
             }
+            // dependence: is a live neighbour an earlier candidate of this round?  Looked up now (only the ids are needed), so
+            // that the cut is known before the sorts: nothing more is prepared for the candidates behind it.
+            int32_t bpk[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) { bpk[k] = -1; if (la[k] && lv[k] > 0) bpk[k] = batch_pos[ln[k]]; }
             // Shortcut for the common column: no appended entries, CSR segment still sorted, all live
             // weights equal, weight order.  Read backwards it is in descending id, so the id rank is a
             // popcount of the live mask; std::sort of all-equal keys is the identity up to 16 entries and a
@@ -1581,7 +1586,16 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     E.val = lv[k]; E.nbr = ln[k];
                 }
             }
-            WAVE_SYNC();   // candidate-local: producer and consumer are the same (half-)wave
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t i = (k * NT + tid) / BCAP;
+                if (bpk[k] >= 0 && bpk[k] < i) atomicMin(&s_pmax, i);
+            }
+            if (tid < nc && (L.cand[tid].flags & CF_BIG)) atomicMin(&s_pmax, tid);
+            __syncthreads();
+            const int32_t ncp = s_pmax < nc ? s_pmax : nc;   // candidates [ncp, nc) are behind the cut
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) if ((k * NT + tid) / BCAP >= ncp) { la[k] = false; ready[k] = false; }
             PHASE_STAMP(9);
             // rank of every live entry among its column's live entries by id: with distinct ids the
             // sorted order is unique, so no std::sort emulation is needed (equal ids -> single-vertex path).
@@ -1600,10 +1614,10 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 // in-place twin rewrites (:404-406) can leave a CSR segment unsorted: the shortcut needs
                 // every slot (live or dead) strictly above its successor
                 const int32_t nxt = __shfl_down(ln[k], 1);
-                const bool unsorted = la[k] && (i < nc) && (e + 1 < L.cand[i].ext) && !(ln[k] > nxt);
+                const bool unsorted = la[k] && (i < ncp) && (e + 1 < L.cand[i].ext) && !(ln[k] > nxt);
                 const uint64_t hbad = (__ballot(unsorted) >> (lane & GSH)) & GMASK;
                 rk[k] = -1;
-                if (!ready[k] && i < nc && L.cand[i].ext > 0) {
+                if (!ready[k] && i < ncp && L.cand[i].ext > 0) {
                     Cand& C = L.cand[i];
                     if (C.acnt == 0 && hbad == 0) {
                         if (live) rk[k] = __popcll(half & ~((2ull << e) - 1ull));
@@ -1733,7 +1747,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 r2[k] = -1;
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, j = idx % BCAP;
-                const bool valid = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP | CF_READY)) && (j < L.cand[i].m);
+                const bool valid = (i < ncp) && !(L.cand[i].flags & (CF_BIG | CF_DUP | CF_READY)) && (j < L.cand[i].m);
                 if (__ballot(valid) == 0ull) continue;
                 double kme = 0, k0 = 0;
                 if (valid) { kme = L.cand[i].e[j].aux; k0 = L.cand[i].e[0].aux; }
@@ -1777,7 +1791,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
 #pragma unroll 1
                 for (int k = 0; k < PASSES; ++k) {
                     const int32_t i = k * NWAVE + (tid >> 6);
-                    if (i >= nc) break;
+                    if (i >= ncp) break;
                     Cand& C = L.cand[i];
                     const int32_t fl = C.flags, m = C.m;
                     if ((fl & (CF_BIG | CF_DUP | CF_READY)) || !(m > 16 && (fl & CF_TIE) && (fl & CF_NEQ))) continue;
@@ -1798,13 +1812,13 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     const int gl = lane & (BC - 1);
                     bool want = false;
                     int32_t m = 0;
-                    if (i < nc) {
+                    if (i < ncp) {
                         const int32_t fl = L.cand[i].flags;
                         m = L.cand[i].m;
                         want = !(fl & (CF_BIG | CF_DUP | CF_READY)) && m > 16 && (fl & CF_TIE) && (fl & CF_NEQ);
                     }
                     if (__ballot(want) == 0ull) continue;
-                    Cand& C = L.cand[i < nc ? i : 0];
+                    Cand& C = L.cand[i < ncp ? i : 0];
                     double key = (want && gl < m) ? C.e[gl].aux : 0.0;
                     int idx = gl, pos = gl;
                     const bool ok = desc ? group_sort<true, BC>(key, idx, m, want, lane, tmp, &pos) : group_sort<false, BC>(key, idx, m, want, lane, tmp, &pos);
@@ -1823,7 +1837,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, j = idx % BCAP;
-                pa[k] = (i < nc) && !(L.cand[i].flags & (CF_BIG | CF_DUP | CF_READY)) && (j < L.cand[i].m);
+                pa[k] = (i < ncp) && !(L.cand[i].flags & (CF_BIG | CF_DUP | CF_READY)) && (j < L.cand[i].m);
                 pv[k] = 0; pn[k] = 0; pt[k] = 0;
                 if (__ballot(pa[k]) == 0ull) continue;
                 if (pa[k]) {
@@ -1852,23 +1866,10 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         for (int k = 0; k < PASSES; ++k) { hkeys[k * NT + tid] = -1; hcnt[k * NT + tid] = 0; }
         if (tid < BATCH) L.cmask[tid] = 0ull;
         // ================= P1b: first candidate that depends on an earlier one =================
-        if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);
-        // the look-ups are issued, then the RNG offsets' scan (P2) runs while they are in flight: a prefix sum does not
-        // depend on what follows it, so it is taken over all candidates of the round before the cut is known
-        int32_t bpk[PASSES];
-#pragma unroll
-        for (int k = 0; k < PASSES; ++k) {
-            const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
-            bpk[k] = -1;
-            if ((i < nc) && (j < L.cand[i].m)) bpk[k] = batch_pos[L.cand[i].e[j].nbr];
-        }
+        if (tid < nc && (L.cand[tid].flags & (CF_BIG | CF_DUP))) atomicMin(&s_pmax, tid);   // (multi-edges show up during the sorts)
+        // RNG offsets (P2): a prefix sum does not depend on what follows it, so it is taken over all candidates of the round
         int dtot;
         const int dex = block_excl_scan<NWAVE>((tid < nc && !first_is_big) ? L.cand[tid].ndraw : 0, L.scan, &dtot);
-#pragma unroll
-        for (int k = 0; k < PASSES; ++k) {
-            const int32_t i = tid / (NT / BATCH);
-            if (bpk[k] >= 0 && bpk[k] < i) atomicMin(&s_pmax, i);
-        }
         __syncthreads();
         const int32_t Pmax = first_is_big ? 0 : (s_pmax < nc ? s_pmax : nc);
         int32_t P = 0;
