@@ -1516,6 +1516,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             cand_meta(A, v, L.cand[tid]);
             L.cand[tid].src = src;
             batch_pos[v] = tid;
+            if (L.cand[tid].flags & CF_BIG) atomicMin(&s_pmax, tid);   // a long column cuts the round: nothing is loaded behind it
         }
         __syncthreads();
         const bool first_is_big = (L.cand[0].flags & CF_BIG) != 0;   // goes to the single-vertex path: skip this round's prepare
@@ -1523,11 +1524,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             // BATCH*BCAP = 4*NT slots: issue every load before the first LDS store
             static_assert(BATCH * BCAP == PASSES * NT && (BC == 32 || BC == 64), "slot loops are unrolled for PASSES passes");
             double lv[PASSES]; int32_t ln[PASSES], lt[PASSES]; bool la[PASSES];
+            const int32_t cut0 = (OV == OV_RANDOM) ? s_pmax : nc;   // o_v = random: the first long column (most rounds have one) is known already
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t idx = k * NT + tid;
                 const int32_t i = idx / BCAP, e = idx % BCAP;
-                la[k] = (i < nc) && (e < L.cand[i].ext);
+                la[k] = (i < nc) && (OV != OV_RANDOM || i < cut0) && (e < L.cand[i].ext);
                 lv[k] = 0; ln[k] = 0; lt[k] = 0;
                 if (la[k]) {
                     int32_t sl = cand_slot(L.cand[i], e);
@@ -1553,7 +1555,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 const bool live = la[k] && lv[k] > 0;
                 const uint64_t half = (__ballot(live) >> hb) & GMASK;
                 const int32_t nxt = __shfl_down(ln[k], 1);
-                const bool cand_ok = (i < nc) && !(L.cand[i].flags & CF_BIG);
+                const bool cand_ok = (i < nc) && (OV != OV_RANDOM || i < cut0) && !(L.cand[i].flags & CF_BIG);
                 const int32_t ext = cand_ok ? L.cand[i].ext : 0;
                 const bool unsorted = la[k] && (e + 1 < ext) && !(ln[k] > nxt);
                 const uint64_t hbad = (__ballot(unsorted) >> hb) & GMASK;
