@@ -2262,15 +2262,20 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 int32_t* const hl_idx = hl_list + HCAP;                       // [HCAP] their places in (candidate, op) order
                 int rank_w = 0;
                 {
-                    const uint64_t lt = lanemask_lt(lane);
-                    uint64_t rem = __ballot(low);
-                    while (rem) {
-                        const int l = __builtin_ctzll(rem);
-                        const uint32_t bb = (uint32_t)__shfl((int)brel, l);
-                        const uint64_t same = __ballot(low && brel == bb);
-                        if (low && brel == bb) rank_w = __popcll(same & lt);
-                        if (lane == l) wtab[(tid >> 6) * RB + bb] = __popcll(same);
-                        rem &= ~same;
+                    // lanes of my wave with my bucket: one ballot per bit of the bucket number (8 bits) instead of a loop
+                    // over the distinct buckets of the wave
+                    static_assert(RB == 256, "8 bits of bucket number");
+                    uint64_t eq = __ballot(low);
+#pragma unroll
+                    for (int bit = 0; bit < 8; ++bit) {
+                        const bool mybit = (brel >> bit) & 1u;
+                        const uint64_t bb = __ballot(low && mybit);
+                        eq &= mybit ? bb : ~bb;
+                    }
+                    if (low) {
+                        const uint64_t before = eq & lanemask_lt(lane);
+                        rank_w = __popcll(before);
+                        if (before == 0ull) wtab[(tid >> 6) * RB + brel] = __popcll(eq);
                     }
                 }
                 if (high) { const int32_t q = atomicAdd(&s_nhigh, 1); if (q < HCAP) { hl_list[q] = list_my; hl_idx[q] = tid; } }
