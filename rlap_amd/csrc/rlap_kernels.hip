@@ -971,14 +971,14 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
         for (int j0 = 0; j0 < m - 1; j0 += 64) {
             const int j = j0 + lane;
             const bool act = j < m - 1;
-            const int x = act ? L.t_of[L.ksel[j]] : (-1 - lane);
-            uint64_t mymask = 0ull, rem = __ballot(act);
-            while (rem) {
-                const int l = __builtin_ctzll(rem);
-                const int xx = __shfl(x, l);
-                const uint64_t same = __ballot(act && x == xx);
-                if (act && x == xx) mymask = same;
-                rem &= ~same;
+            const int x = act ? L.t_of[L.ksel[j]] : 0;
+            uint64_t mymask = __ballot(act);   // lanes that drew my target: one ballot per bit of its index (< ECAP <= 512)
+            static_assert(ECAP <= 512, "9 bits of target index");
+#pragma unroll
+            for (int bit = 0; bit < 9; ++bit) {
+                const bool mybit = (x >> bit) & 1;
+                const uint64_t bb = __ballot(act && mybit);
+                mymask &= mybit ? bb : ~bb;
             }
             if (act && lane == __builtin_ctzll(mymask)) {
                 int32_t a = L.t_cnt[x], chunk = L.t_chunk[x];
@@ -1239,14 +1239,15 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
     for (int j0 = 0; j0 < m - 1; j0 += 64) {
         const int j = j0 + lane;
         const bool act = j < m - 1;
-        const int32_t k = act ? B.a_nbr[B.ksel[j]] : (-1 - lane);
-        uint64_t mymask = 0ull, rem = __ballot(act);
-        while (rem) {
-            const int l = __builtin_ctzll(rem);
-            const int32_t kk = __shfl(k, l);
-            const uint64_t same = __ballot(act && k == kk);
-            if (act && k == kk) mymask = same;
-            rem &= ~same;
+        const int32_t ks = act ? B.ksel[j] : 0;
+        const int32_t k = act ? B.a_nbr[ks] : -1;
+        uint64_t mymask = __ballot(act);   // lanes that drew my target: one ballot per bit of its position (< BIGE <= 8192)
+        static_assert(BIGE <= 8192, "13 bits of target position");
+#pragma unroll
+        for (int bit = 0; bit < 13; ++bit) {
+            const bool mybit = (ks >> bit) & 1;
+            const uint64_t bb = __ballot(act && mybit);
+            mymask &= mybit ? bb : ~bb;
         }
         if (act && lane == __builtin_ctzll(mymask)) {
             int32_t a = ld_agent(&A.app_cnt[k]), chunk = ld_agent(&A.app_chunk[k]);
