@@ -2218,7 +2218,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             //      the candidates' move counts summed before it plus the rank of its op bit in its candidate's mask;
             //      the moves are laid out in that order, then each finds its rank inside its bucket by counting
             //      (64 buckets above the lowest through a per-wave table, the few beyond -- hubs -- by comparing
-            //      among themselves).  Falls back to the bitonic sort when more than 64 moves go beyond. ----
+            //      among themselves).  Falls back to the bitonic sort when more than 128 moves go beyond. ----
             const bool mine = tid < nmoves;
             int32_t list_my = 0, x_my = -1, rank_my = 0, pos_my = 0;
             bool tail_my = false;
