@@ -65,8 +65,8 @@ def main():
     def step():
         sc = ops.approximate_cholesky(ei, w_dev, n, t, args.o_v, args.o_n, perm=perm, seed=7, return_device="same")
         if world > 1 and not args.no_gather:
-            from rlap_amd.distributed import all_gather_rows
-            sc, _ = all_gather_rows(sc)
+            from rlap_amd.distributed import all_gather_edge_rows
+            sc, _ = all_gather_edge_rows(sc)
         return sc
 
     def sync():

@@ -47,6 +47,19 @@ def all_gather_rows(local: torch.Tensor, group=None) -> Tuple[torch.Tensor, torc
     return out, counts_h
 
 
+def all_gather_edge_rows(sc: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather of (m_r, 3) f64 [row, col, w] blocks with the two node ids packed into one 64-bit word for the
+    exchange: 16 bytes per row over xGMI instead of 24.  Returns the same (cat, counts) as all_gather_rows."""
+    ids = (sc[:, 0].to(torch.int64) << 32) | sc[:, 1].to(torch.int64)
+    packed = torch.stack([ids, sc[:, 2].contiguous().view(torch.int64)], dim=1)
+    allp, counts = all_gather_rows(packed, group=group)
+    out = torch.empty((allp.shape[0], 3), dtype=torch.float64, device=sc.device)
+    out[:, 0] = (allp[:, 0] >> 32).to(torch.float64)
+    out[:, 1] = (allp[:, 0] & 0xFFFFFFFF).to(torch.float64)
+    out[:, 2] = allp[:, 1].contiguous().view(torch.float64)
+    return out, counts
+
+
 def sharded_approximate_cholesky(
     edge_indices: Sequence[torch.Tensor],
     edge_weights: Optional[Sequence[Optional[torch.Tensor]]],

@@ -79,6 +79,37 @@ def test_sharded_batched_mode_world2():
     assert ret[0][2] == (0, 3) and ret[1][2] == (3, 5)
 
 
+def _worker_edge_rows(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rlap_amd.distributed import all_gather_edge_rows, all_gather_rows
+    rs = np.random.RandomState(100 + rank)
+    m = [7, 0, 12][rank]                       # ragged, one rank empty
+    sc = torch.from_numpy(np.stack([rs.randint(0, 1 << 30, m).astype(np.float64), rs.randint(0, 1 << 30, m).astype(np.float64),
+                                    rs.rand(m)], axis=1).reshape(m, 3))
+    a, ca = all_gather_edge_rows(sc)
+    b, cb = all_gather_rows(sc)
+    ret[rank] = (a.numpy(), ca.numpy(), b.numpy(), cb.numpy())
+    dist.destroy_process_group()
+
+
+def test_packed_edge_row_exchange_world3():
+    """bench.py --gpus N exchanges sc_edge_info with the two node ids packed into one word (16 B per row): the
+    result equals the plain all-gather bit for bit, with ragged and empty blocks."""
+    world = 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_edge_rows, args=(world, port, ret), nprocs=world, join=True)
+    for rank in range(world):
+        a, ca, b, cb = ret[rank]
+        assert np.array_equal(ca, cb) and list(ca) == [7, 0, 12]
+        assert a.shape == b.shape == (19, 3) and np.array_equal(a, b)
+    assert np.array_equal(ret[0][0], ret[2][0])
+
+
 def test_shard_range_partitions_everything():
     from rlap_amd.distributed import shard_range
     for G in (0, 1, 7, 8, 1024):
