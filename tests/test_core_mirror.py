@@ -36,6 +36,17 @@ def test_std_sort_emulation_matches_libstdcxx(host_mirror):
             assert np.array_equal(oracle.stdsort_perm(k, bool(desc)), _mperm(host_mirror, "mirror_sort_perm", k, desc))
 
 
+def test_depth_limit_branch_matches_libstdcxx(host_mirror):
+    """Adversarial keys (util.introsort_killer) push std::sort into its heap-sort branch: the restatement follows."""
+    from util import introsort_killer
+    for n in (40, 64, 100, 200, 384, 512, 3000):
+        k, hit = introsort_killer(n)
+        assert hit
+        for keys in (k, -k, np.concatenate([k, k[: n // 3]])):   # distinct, mirrored for the descending comparator, with ties
+            for desc in (0, 1):
+                assert np.array_equal(oracle.stdsort_perm(keys, bool(desc)), _mperm(host_mirror, "mirror_sort_perm", keys, desc)), (n, desc)
+
+
 def test_small_stack_free_sort_matches_libstdcxx(host_mirror):
     rng = np.random.RandomState(2)
     for trial in range(3000):

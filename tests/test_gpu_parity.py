@@ -91,6 +91,58 @@ def test_wave_parallel_std_sort_matches_libstdcxx(ops):
             assert np.array_equal(got[offs[a_i]:offs[a_i + 1]], exp), (a_i, len(k), desc)
 
 
+def test_sorts_follow_the_depth_limit_branch(ops):
+    """Adversarial keys that push libstdc++'s introsort into its heap-sort branch (util.introsort_killer): the LDS
+    variant follows it; the register variants report it (the kernels then take the sequential restatement)."""
+    from util import introsort_killer
+    arrays, hits = [], []
+    for n in (33, 40, 64, 100, 200, 384, 512):
+        k, hit = introsort_killer(n)
+        for keys in (k, -k, np.concatenate([k, k[: n // 3]])[:512]):
+            arrays.append(keys); hits.append(hit)
+    offs = np.zeros(len(arrays) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(a) for a in arrays])
+    keys = torch.from_numpy(np.concatenate(arrays)).cuda()
+    offs_t = torch.from_numpy(offs).cuda()
+    lib, h = ops._handle(torch.device("cuda", 0))
+    for desc in (0, 1, 2, 3):
+        out = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device="cuda")
+        assert lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr()) == 0
+        got = out.cpu().numpy()
+        for a_i, k in enumerate(arrays):
+            exp = oracle.stdsort_perm(k, bool(desc & 1))
+            g = got[offs[a_i]:offs[a_i + 1]]
+            if (desc & 2) and len(k) <= 64 and (g == -1).all():
+                continue   # register variant: depth limit reported
+            assert np.array_equal(g, exp), (a_i, len(k), desc)
+
+
+def test_killer_weights_through_the_op(ops):
+    """Weights that are an introsort killer: the o_n order of a long surviving column (output pass) and of a long
+    eliminated column (single-vertex path) goes through the heap-sort branch of the restatement."""
+    from util import introsort_killer
+    for n in (120, 300, 700, 2500):
+        ei = star(n)
+        k, hit = introsort_killer(n - 1)
+        assert hit
+        deg = np.bincount(ei[0], minlength=n)
+        hub = int(np.argmax(deg))
+        w = np.empty(ei.shape[1])
+        leaf = np.where(ei[0] == hub, ei[1], ei[0])          # the leaf of every directed entry
+        rank_of_leaf = {int(v): i for i, v in enumerate(sorted(set(leaf.tolist())))}
+        for ties in (False, True):   # with ties the single-vertex path cannot use a stable rank and runs the restatement too
+          kk = np.floor(k / 2) if ties else k
+          w[:] = [1.0 + kk[rank_of_leaf[int(v)]] for v in leaf]   # positive, symmetric (distinct per undirected edge without ties)
+          for o_n in ("asc", "desc"):
+            a = oracle.approximate_cholesky(ei, w, n, 0, "degree", o_n)            # hub survives: output pass
+            b = gpu_call(ops, ei, w, n, 0, "degree", o_n)
+            assert_same(b, a, f"killer star{n} output {o_n} ties={ties}")
+            perm = np.array([v for v in range(n) if v != hub] + [hub])             # hub popped first (from the back)
+            a = oracle.approximate_cholesky(ei, w, n, 5, "random", o_n, perm=perm)
+            b = gpu_call(ops, ei, w, n, 5, "random", o_n, perm=perm)
+            assert_same(b, a, f"killer star{n} eliminated {o_n} ties={ties}")
+
+
 def test_identity_round_trip(ops):
     # reference tests/test_rlap.py:12-20
     for _ in range(3):

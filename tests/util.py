@@ -71,3 +71,66 @@ def canonical(sc):
         return sc
     order = np.lexsort((sc[:, 0], sc[:, 1]))
     return sc[order]
+
+
+def introsort_killer(n):
+    """Keys (distinct ints as float64) that drive libstdc++'s std::sort (threshold 16, median-of-3 to first, unguarded
+    Hoare partition, depth limit 2*floor(log2 n)) into its heap-sort branch: McIlroy's adversary ("A Killer Adversary for
+    Quicksort", 1999) run against a restatement of the introsort loop.  Returns (keys, hit_depth_limit)."""
+    GAS = 1 << 60
+    val = [GAS] * n
+    state = {"nsolid": 0, "cand": 0}
+
+    def less(x, y):   # x, y: item ids
+        if val[x] == GAS and val[y] == GAS:
+            if x == state["cand"]:
+                val[x] = state["nsolid"]
+            else:
+                val[y] = state["nsolid"]
+            state["nsolid"] += 1
+        if val[x] == GAS:
+            state["cand"] = x
+        elif val[y] == GAS:
+            state["cand"] = y
+        return val[x] < val[y]
+
+    a = list(range(n))
+    depth0 = 2 * (n.bit_length() - 1)
+    hit = False
+    stack = [(0, n, depth0)]
+    while stack:
+        first, last, depth = stack.pop()
+        while last - first > 16:
+            if depth == 0:
+                hit = True
+                break
+            depth -= 1
+            ia, ib, ic = first + 1, first + (last - first) // 2, last - 1
+            if less(a[ia], a[ib]):
+                pick = ib if less(a[ib], a[ic]) else (ic if less(a[ia], a[ic]) else ia)
+            elif less(a[ia], a[ic]):
+                pick = ia
+            elif less(a[ib], a[ic]):
+                pick = ic
+            else:
+                pick = ib
+            a[first], a[pick] = a[pick], a[first]
+            pv = a[first]
+            f, l = first + 1, last
+            while True:
+                while less(a[f], pv):
+                    f += 1
+                l -= 1
+                while less(pv, a[l]):
+                    l -= 1
+                if not f < l:
+                    break
+                a[f], a[l] = a[l], a[f]
+                f += 1
+            stack.append((f, last, depth))
+            last = f
+    for i in range(n):
+        if val[i] == GAS:
+            val[i] = state["nsolid"]
+            state["nsolid"] += 1
+    return np.array(val, dtype=np.float64), hit
