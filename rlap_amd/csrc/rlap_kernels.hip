@@ -1438,6 +1438,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     if (nelim < 0) nelim = 0;
     int64_t done = 0;
     int32_t rounds = 0, singles = 0;
+    bool pending_long = false;   // o_v = random: the last round was cut by a long column, which is therefore the next vertex
     long long t_prev = 0;
     __shared__ long long s_prof[40];   // diagnostic build only (S.prof != nullptr)
 #define PHASE_STAMP(k) do { if (S.prof && tid == 0 && g == 0) { long long _t = wall_clock64(); s_prof[k] += _t - t_prev; t_prev = _t; } } while (0)
@@ -1452,6 +1453,30 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         asm volatile("" : "+v"(tid_round));
         const int tid = tid_round;
         const int lane = tid & 63;
+        if (OV == OV_RANDOM && pending_long) {
+            // the vertex that cut the previous round goes straight to the single-vertex path: no round is set up around it
+            pending_long = false;
+            ++singles;
+            const int32_t v0 = G.vbase + (int32_t)A.perm[G.vbase + n - (done + 1)];
+            if (tid < 64) {
+                Arrays A2 = A;
+                ElimScratch S2 = S;
+                int32_t cp0 = A2.colptr[v0], cp1 = A2.colptr[v0 + 1];
+                int32_t acnt = A2.app_cnt[v0], abase = A2.app_chunk[v0];
+                if ((cp1 - cp0) + acnt > ECAP) {
+                    ColBuf Bf = S2.colbuf(G.scr_base);
+                    const bool handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
+                    if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
+                } else {
+                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr);
+                }
+            }
+            __syncthreads();
+            if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
+            done += 1;
+            PHASE_STAMP(5);
+            continue;
+        }
         ++rounds;
         const int32_t Bcur = (int32_t)((nelim - done) < (int64_t)BATCH ? (nelim - done) : (int64_t)BATCH);
         // ================= P0: predict the next pops =================
@@ -2461,6 +2486,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0;
         }
         done += P;
+        pending_long = (OV == OV_RANDOM) && P < nc && (L.cand[P].flags & CF_BIG) != 0;
         __syncthreads();
     }
     __syncthreads();
