@@ -9,8 +9,13 @@
  *             (reference: rlap/csrc/py_api_binder.cc:71-76)
  * which are what rlap/ops.py:52-58 and :61-63 call.  Plain pointers and sizes
  * only; every array pointer is DEVICE memory unless its name starts with h_.
- * All work is enqueued on the handle's HIP stream; the call returns after the
- * (few) scalars it reports have been copied back.
+ * All work is enqueued on the handle's HIP stream without any host synchronisation
+ * in between (every workspace size is an upper bound computed from E, n and G; input
+ * checks and growth limits are evaluated by the kernels); the call returns after ONE
+ * read-back of the scalars it reports.
+ * Threading: a handle owns its workspace and serialises the calls made on it (a mutex);
+ * for concurrent calls give every host thread its own handle (and stream) -- the
+ * reference builds a fresh ApproximateCholesky per call (py_api_binder.cc:57).
  */
 #ifndef RLAP_HIP_H
 #define RLAP_HIP_H
@@ -55,6 +60,10 @@ typedef struct {
     float ms_sc_merge;    /* output pass A alone                              */
     float ms_sc_compact;  /* output pass B alone (ballot/prefix compaction)   */
     float ms_total;
+    int32_t n_retries;    /* times the call was repeated with a larger workspace (RLAP_E_*_OVERFLOW inside) */
+    int32_t reserved;
+    int64_t n_rounds;     /* elimination: batch rounds, summed over graphs              */
+    int64_t n_singles;    /* elimination: vertices that took the single-vertex path     */
 } rlap_stats;
 
 /* Lifetime.  A handle binds to the HIP device current at creation and owns a
@@ -81,7 +90,9 @@ int rlap_unpack_edge_info(rlap_handle h, const double* d_edge_info, int64_t E, i
  *   n, t            : num_nodes, num_remove
  *   d_perm          : o_v=random only: the node_id vector (a permutation of
  *                     0..n-1) popped from the BACK (preconditioner.cc:588-613);
- *                     the reference draws it from std::random_device
+ *                     the reference draws it from std::random_device.  Checked on
+ *                     the device: anything but a permutation gives RLAP_E_BAD_ARG.
+ *                     NULL = drawn on the device from shuffle_seed (keyed shuffle)
  *   shuffle_seed    : o_n=random / o_v=coarsen only: seed of the keyed neighbour
  *                     order that stands in for std::shuffle(random_device)
  *   d_out           : (out_cap_rows,3) f64 row-major [row, col, w]
@@ -93,13 +104,35 @@ int rlap_approx_chol(rlap_handle h, const int64_t* d_row, const int64_t* d_col, 
 /* Batched graphs (a disjoint union): graph g owns the node ids
  * [h_node_ptr[g], h_node_ptr[g+1]); no edge may cross graphs.  Each graph is
  * eliminated independently with its own num_remove and its own restart of the
- * sampling stream -- what G separate reference calls would do.  d_perm holds,
- * for graph g, a permutation of LOCAL ids 0..n_g-1 at [node_ptr[g], node_ptr[g+1]).
+ * sampling stream -- what G separate reference calls would do: the rows of graph g
+ * are those of rlap_approx_chol on graph g alone (ids shifted by node_ptr[g]) with
+ * its slice of d_perm and with shuffle_seed + g (the keyed neighbour order hashes
+ * graph-local ids).  d_perm holds, for graph g, a permutation of LOCAL ids
+ * 0..n_g-1 at [node_ptr[g], node_ptr[g+1]).
  * Rows come out grouped by graph, with global node ids; h_out_row_ptr[G+1]. */
 int rlap_approx_chol_batched(rlap_handle h, const int64_t* d_row, const int64_t* d_col, const double* d_w, int64_t E,
                              int64_t G, const int64_t* h_node_ptr, const int64_t* h_num_remove, int o_v, int o_n,
                              const int64_t* d_perm, uint64_t shuffle_seed, double* d_out, int64_t out_cap_rows,
                              int64_t* h_out_row_ptr, rlap_stats* h_stats);
+
+/* The op with the step BEFORE the path fused in (scripts/node_shared.py:326-327,
+ * scripts/augmentor_benchmarks.py:77-78):
+ *   symmetrize != 0 : the input holds every undirected edge in one or both directions; (b,a) is
+ *                     added for every (a,b) and duplicates are folded inside the COO->CSR kernels
+ *                     (PyG to_undirected + coalesce: an edge SET with unit weights when d_w is
+ *                     NULL, summed weights otherwise).  out_cap_rows must allow 2*E rows.
+ *   n < 0           : num_nodes = max id + 1, found on the device (one 8-byte read-back)
+ *   t < 0           : num_remove = (int64)(remove_frac * num_nodes)
+ *   h_num_nodes     : (nullable) the num_nodes used */
+int rlap_approx_chol_from_edges(rlap_handle h, const int64_t* d_src, const int64_t* d_dst, const double* d_w, int64_t E,
+                                int64_t n, int64_t t, double remove_frac, int symmetrize, int o_v, int o_n,
+                                const int64_t* d_perm, uint64_t shuffle_seed, double* d_out, int64_t out_cap_rows,
+                                int64_t* h_out_rows, int64_t* h_num_nodes, rlap_stats* h_stats);
+
+/* Test hook: first-attempt limits for the next calls on this handle (negative = default): append-pool factor,
+ * PQ-log factor, length of the uniform table the kernels may use, entries of the output pass's long-column
+ * scratch.  A call that runs into one of them repeats itself with the regular sizes (rlap_stats.n_retries). */
+int rlap_debug_set_limits(rlap_handle h, double pool_factor, double log_factor, int64_t rng_len, int64_t scratch_entries);
 
 /* First `count` uniforms of the sampling stream (default-seeded std::mt19937_64
  * through uniform_real_distribution<double>(0,1), preconditioner.cc:356-357)

@@ -8,6 +8,7 @@ from .pyoracle import (  # noqa: F401
     build,
     stdsort_perm,
     heapsort_perm,
+    keyed_order,
     uniforms,
     O_V,
     O_N,

@@ -49,6 +49,7 @@ def _load():
         lib.rlap_oracle_uniforms.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         lib.rlap_oracle_stdsort_perm.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
         lib.rlap_oracle_heapsort_perm.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+        lib.rlap_oracle_keyed_keys.argtypes = [ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -120,3 +121,12 @@ def heapsort_perm(keys, desc=False):
     p = np.empty(k.shape[0], dtype=np.int64)
     lib.rlap_oracle_heapsort_perm(k.ctypes.data, k.shape[0], 1 if desc else 0, p.ctypes.data)
     return p
+
+
+def keyed_order(seed, vertex, phase, nbrs):
+    """Positions of the injected neighbour order: returns the neighbours' indices in the order they are visited."""
+    lib = _load()
+    nb = np.ascontiguousarray(np.asarray(nbrs, dtype=np.int64))
+    k = np.empty(nb.shape[0], dtype=np.float64)
+    lib.rlap_oracle_keyed_keys(int(seed) & (2**64 - 1), int(vertex), int(phase), nb.ctypes.data, nb.shape[0], k.ctypes.data)
+    return stdsort_perm(k), k

@@ -550,6 +550,13 @@ void rlap_oracle_stdsort_perm(const double* keys, int64_t cnt, int desc, int64_t
     for (int64_t i = 0; i < cnt; ++i) perm_out[i] = v[i].i;
 }
 
+// The injected neighbour order (stands in for std::shuffle(random_device), preconditioner.cc:303-307):
+// keys of the neighbours `nbrs` of `vertex`; the order is std::sort ascending on them.  For the statistical
+// test of tests/test_keyed_order.py.
+void rlap_oracle_keyed_keys(uint64_t seed, int64_t vertex, int phase, const int64_t* nbrs, int64_t cnt, double* keys_out) {
+    for (int64_t i = 0; i < cnt; ++i) keys_out[i] = keyed_order_dkey(seed, vertex, phase, nbrs[i]);
+}
+
 // std::partial_sort(first,last,last) (= introsort's depth-limit fallback) permutation.
 void rlap_oracle_heapsort_perm(const double* keys, int64_t cnt, int desc, int64_t* perm_out) {
     struct P { double k; int64_t i; };

@@ -16,6 +16,7 @@ EXPORTS = [
     "rlap_create", "rlap_destroy", "rlap_set_stream", "rlap_set_timing", "rlap_status_string",
     "rlap_identity", "rlap_unpack_edge_info", "rlap_approx_chol", "rlap_approx_chol_batched",
     "rlap_rng_uniforms", "rlap_util_ba_graph", "rlap_debug_wave_sort",
+    "rlap_approx_chol_from_edges", "rlap_debug_set_limits",
 ]
 
 
@@ -25,6 +26,8 @@ class Stats(ctypes.Structure):
         ("out_rows", ctypes.c_int64), ("live_entries", ctypes.c_int64),
         ("ms_setup", ctypes.c_float), ("ms_elim", ctypes.c_float), ("ms_output", ctypes.c_float),
         ("ms_sc_merge", ctypes.c_float), ("ms_sc_compact", ctypes.c_float), ("ms_total", ctypes.c_float),
+        ("n_retries", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("n_rounds", ctypes.c_int64), ("n_singles", ctypes.c_int64),
     ]
 
     def as_dict(self):
@@ -62,6 +65,11 @@ def load():
     lib.rlap_approx_chol_batched.restype = ci
     lib.rlap_approx_chol_batched.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, ci, ci, vp, u64, vp, i64, vp,
                                              ctypes.POINTER(Stats)]
+    lib.rlap_approx_chol_from_edges.restype = ci
+    lib.rlap_approx_chol_from_edges.argtypes = [vp, vp, vp, vp, i64, i64, i64, ctypes.c_double, ci, ci, ci, vp, u64, vp, i64,
+                                                ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(Stats)]
+    lib.rlap_debug_set_limits.restype = ci
+    lib.rlap_debug_set_limits.argtypes = [vp, ctypes.c_double, ctypes.c_double, i64, i64]
     lib.rlap_rng_uniforms.restype = ci
     lib.rlap_rng_uniforms.argtypes = [vp, i64, vp]
     lib.rlap_debug_wave_sort.restype = ci

@@ -16,11 +16,14 @@ from . import ops
 Graph = namedtuple("Graph", ["x", "edge_index", "edge_weights"])
 
 
-def _num_nodes(edge_index: torch.Tensor, x: Optional[torch.Tensor]) -> int:
-    if x is not None:
-        return int(x.shape[0])
-    # reference: edge_index.max().item() + 1 (augmentor_benchmarks.py:77) -- one host sync
-    return int(edge_index.max().item()) + 1 if edge_index.numel() else 0
+def _schur(edge_index, edge_weights, x, frac, o_v, o_n, seed, num_nodes_from_x, symmetrize):
+    """One call of the op the way the reference adapters make it: num_nodes = edge_index.max() + 1 and
+    num_remove = int(frac * num_nodes) (scripts/augmentor_benchmarks.py:77-78), both found inside the C ABI
+    (no torch reduction, no `.item()`).  `num_nodes_from_x=True` is the explicit opt-in to x.shape[0] instead
+    (differs from the reference when the trailing nodes are isolated: more vertices enter the queue)."""
+    n = int(x.shape[0]) if (num_nodes_from_x and x is not None) else None
+    return ops.approximate_cholesky_from_edges(edge_index, edge_weights, n, None, o_v, o_n, remove_frac=frac,
+                                               symmetrize=symmetrize, seed=seed, return_device="same")
 
 
 class rLap:
@@ -31,19 +34,20 @@ class rLap:
     keep_weights=True.
     """
 
-    def __init__(self, frac: float, o_v: str = "random", o_n: str = "asc", keep_weights: bool = False, seed: Optional[int] = None):
+    def __init__(self, frac: float, o_v: str = "random", o_n: str = "asc", keep_weights: bool = False, seed: Optional[int] = None,
+                 num_nodes_from_x: bool = False, symmetrize: bool = False):
         self.frac = frac
         self.o_v = o_v
         self.o_n = o_n
         self.keep_weights = keep_weights
         self.seed = seed
+        self.num_nodes_from_x = num_nodes_from_x
+        self.symmetrize = symmetrize      # True: one-directional input is made undirected inside the op (fused to_undirected)
 
     def augment(self, g):
         x, edge_index, edge_weights = g.unfold() if hasattr(g, "unfold") else g
-        num_nodes = _num_nodes(edge_index, x)
-        num_remove = int(self.frac * num_nodes)
-        sc = ops.approximate_cholesky(edge_index, edge_weights, num_nodes, num_remove, self.o_v, self.o_n,
-                                      seed=self.seed, return_device="same")
+        sc, num_nodes = _schur(edge_index, edge_weights, x, self.frac, self.o_v, self.o_n, self.seed, self.num_nodes_from_x, self.symmetrize)
+        self.num_remove = int(self.frac * num_nodes)
         sampled_edge_index = sc[:, :2].long().t().contiguous()          # stays on the device
         w = sc[:, 2].contiguous() if self.keep_weights else None
         try:  # PyGCL present: return its Graph type
@@ -57,12 +61,19 @@ class rLap:
 
 
 def compute_ppr(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int, alpha: float = 0.2,
-                eps: float = 1e-4, add_self_loop: bool = False):
+                eps: float = 1e-4, add_self_loop: bool = False, normalize_out: bool = True):
     """Dense personalised-PageRank diffusion, S = alpha (I - (1-alpha) D^-1/2 A D^-1/2)^-1, entries
-    below `eps` dropped -- the closed form PyGCL's `compute_ppr` evaluates
-    (scripts/augmentor_benchmarks.py:152-159 calls it with ignore_edge_attr=False,
-    add_self_loop=False).  torch ops on the input's device; meant for the sizes the reference
-    uses it on (the Schur-complement subgraph)."""
+    below `eps` dropped, then (normalize_out) the kept entries normalised symmetrically once more,
+    D_S^-1/2 S D_S^-1/2 with D_S the row sums of the thresholded matrix.
+
+    This restates PyGCL's `GCL.augmentors.functional.compute_ppr` (called by
+    scripts/augmentor_benchmarks.py:152-159 with ignore_edge_attr=False, add_self_loop=False), which chains
+    PyG's GDC steps: transition_matrix('sym') -> diffusion_matrix_exact('ppr') -> sparsify_dense('threshold')
+    -> transition_matrix('sym').  PyGCL and PyG are third-party packages absent from this container
+    (PyGCL is unpinned in the reference's requirements.txt), so this row is UNPINNED: it follows the published
+    semantics of those functions, not a run of them.  `normalize_out=False` gives
+    the diffusion matrix before the last step.  torch ops on the input's device; meant for the sizes the
+    reference uses it on (the Schur-complement subgraph)."""
     dev = edge_index.device
     w = torch.ones(edge_index.shape[1], dtype=torch.float64, device=dev) if edge_weight is None else edge_weight.to(torch.float64)
     adj = torch.zeros((num_nodes, num_nodes), dtype=torch.float64, device=dev)
@@ -74,6 +85,10 @@ def compute_ppr(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], n
     a_hat = dinv[:, None] * adj * dinv[None, :]
     s = alpha * torch.linalg.inv(torch.eye(num_nodes, dtype=torch.float64, device=dev) - (1 - alpha) * a_hat)
     s = torch.where(s >= eps, s, torch.zeros_like(s))
+    if normalize_out:
+        d2 = s.sum(1)
+        d2inv = torch.where(d2 > 0, d2.pow(-0.5), torch.zeros_like(d2))
+        s = d2inv[:, None] * s * d2inv[None, :]
     idx = s.nonzero(as_tuple=False).t().contiguous()
     return idx, s[idx[0], idx[1]]
 
@@ -83,25 +98,26 @@ class rLapPPRDiffusion:
     the surviving nodes, relabelled -> PPR diffusion -> original ids; result cached for
     `refresh_cache_freq` calls like the reference."""
 
-    def __init__(self, frac, o_v="random", o_n="asc", alpha=0.2, eps=1e-4, use_cache=True, refresh_cache_freq=50, seed=None):
+    def __init__(self, frac, o_v="random", o_n="asc", alpha=0.2, eps=1e-4, use_cache=True, refresh_cache_freq=50, seed=None,
+                 num_nodes_from_x=False, normalize_out=True):
         self.frac, self.o_v, self.o_n, self.alpha, self.eps = frac, o_v, o_n, alpha, eps
         self.use_cache, self.refresh_cache_freq = use_cache, refresh_cache_freq
         self._cache, self.refresh_cache_counter, self.seed = None, 0, seed
+        self.num_nodes_from_x, self.normalize_out = num_nodes_from_x, normalize_out
 
     def augment(self, g):
         if self._cache is not None and self.use_cache and self.refresh_cache_counter < self.refresh_cache_freq:
             self.refresh_cache_counter += 1
             return self._cache
         x, edge_index, edge_weights = g.unfold() if hasattr(g, "unfold") else g
-        num_nodes = _num_nodes(edge_index, x)
-        sc = ops.approximate_cholesky(edge_index, edge_weights, num_nodes, int(self.frac * num_nodes), self.o_v, self.o_n,
-                                      seed=self.seed, return_device="same")
+        sc, num_nodes = _schur(edge_index, edge_weights, x, self.frac, self.o_v, self.o_n, self.seed, self.num_nodes_from_x, False)
+        self.num_remove = int(self.frac * num_nodes)
         ei = sc[:, :2].long().t()
         nodes = torch.unique(ei, sorted=True)                       # surviving nodes that still have edges
         relabel = torch.full((num_nodes,), -1, dtype=torch.int64, device=ei.device)
         relabel[nodes] = torch.arange(nodes.numel(), device=ei.device)
         sub_ei = relabel[ei]
-        d_ei, d_w = compute_ppr(sub_ei, sc[:, 2], nodes.numel(), alpha=self.alpha, eps=self.eps)
+        d_ei, d_w = compute_ppr(sub_ei, sc[:, 2], nodes.numel(), alpha=self.alpha, eps=self.eps, normalize_out=self.normalize_out)
         res = Graph(x, nodes[d_ei], d_w)
         self._cache, self.refresh_cache_counter = res, 0
         return res

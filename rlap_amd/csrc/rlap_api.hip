@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -45,11 +46,14 @@ inline unsigned nblk(int64_t n, int bs) { return (unsigned)std::max<int64_t>(1, 
 
 struct rlap_handle_s {
     int device = 0;
+    int n_cu = 0;                 // compute units of `device`
+    bool big_attr_set = false;    // k_sc_merge_big's 128 KB dynamic-LDS opt-in (a per-device function attribute)
+    std::mutex mu;                // one call at a time per handle (the workspace is the handle's); use one handle per host thread for concurrency
     hipStream_t stream = nullptr;
     bool timing = false;
     hipEvent_t ev[8];
     // setup
-    DevBuf node_ptr_d, vgraph, flags, acc, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, gcol;
+    DevBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, permchk, genperm;
     // graph state
     DevBuf e_nbr, e_val, e_twin, app_cnt, app_chunk, key, pqpos, ocur, oend, origpos, orig_order, gd_d, pool_top;
     DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, prof;
@@ -58,18 +62,35 @@ struct rlap_handle_s {
     int64_t rng_len = 0;
     DevBuf scr_rec, scr_i32, scr_f64;
     // output
-    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, counters, biglist, biglists, hugelists;
+    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, biglist, biglists, hugelists, results;
+    // pinned host mirror of what a call reads back
+    void* h_results = nullptr; size_t h_results_cap = 0;
     // growth factors kept across calls
     double pool_factor = 1.0;
     double log_factor = 2.0;
+    int64_t rng_min = 0;          // lower bound of the uniform table (grown after an overflow)
+    int64_t scr_budget = 1 << 18; // output pass: entries of global scratch for columns beyond 8192 slots
+    // test hooks (rlap_debug_set_limits): tiny first sizes so that the retry path runs
+    double dbg_pool = -1.0, dbg_log = -1.0; int64_t dbg_rng = -1, dbg_scr = -1;
+    int64_t total_retries = 0;
 };
 
 namespace {
+
+// device-side scalars of a call, zeroed by one memset
+struct Scalars {
+    int32_t flags[FLAG_COUNT];
+    int32_t nnz; int32_t pad;
+    double acc[4];
+    unsigned long long counters[8];   // [0] sc scratch top, [1] live total, [4..6] tier counts (6 ints)
+    unsigned long long maxid;
+};
 
 int ensure_rng(rlap_handle h, int64_t count) {
     if (count <= h->rng_len) return RLAP_OK;
     int64_t want = std::max<int64_t>(count, 1 << 16);
     ENSURE(h->rng, sizeof(double) * (size_t)want);
+    want = (int64_t)(h->rng.cap / sizeof(double));
     hipLaunchKernelGGL(k_mt19937_64_table, dim3(1), dim3(320), 0, h->stream, h->rng.as<double>(), want);
     HIPCHK(hipGetLastError());
     h->rng_len = want;
@@ -96,17 +117,35 @@ int excl_scan(rlap_handle h, In* in, Out* out, int64_t n) {
     return RLAP_OK;
 }
 
-__global__ void k_gather_i32(const int32_t* __restrict__ src, const int64_t* __restrict__ index, int32_t n, int32_t* __restrict__ dst) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[index[i]];
-}
+inline unsigned bits_for(uint64_t maxval) { unsigned b = 1; while (b < 64 && (maxval >> b) != 0) ++b; return b; }
 
-__global__ void k_ext_totals(const int32_t* __restrict__ ext, int32_t S, int32_t thresh, unsigned long long* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long big = 0;
-    if (i < S) { int32_t e = ext[i]; if (e > thresh) big = (unsigned long long)e; }
-    for (int off = 32; off > 0; off >>= 1) big += __shfl_down(big, off);
-    if ((threadIdx.x & 63) == 0 && big) atomicAdd(out, big);
+struct Fills {
+    FillJobs J; int64_t maxcount = 0;
+    Fills() { J.n = 0; }
+    void add(void* p, int64_t count_i32, int32_t v) { if (count_i32 <= 0) return; J.ptr[J.n] = (int32_t*)p; J.count[J.n] = count_i32; J.value[J.n] = v; ++J.n; maxcount = std::max(maxcount, count_i32); }
+    void launch(hipStream_t s) {
+        if (J.n == 0) return;
+        unsigned gx = (unsigned)std::min<int64_t>((maxcount + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_fill_multi, dim3(gx, (unsigned)J.n), dim3(256), 0, s, J);
+        J.n = 0; maxcount = 0;
+    }
+};
+
+// keyed random permutation of each graph's local ids, drawn on the device (stands in for the
+// std::shuffle(random_device) of preconditioner.cc:594-596 when the caller injects no node_id vector)
+__global__ void k_perm_keys(const int32_t* __restrict__ vgraph, const GraphDesc* __restrict__ gd, int32_t N, uint64_t seed,
+                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t g = vgraph[i];
+    const uint32_t local = (uint32_t)(i - gd[g].vbase);
+    // (graph, 32 hash bits) -- ties between equal hashes are broken by the stable radix sort (input order)
+    keys[i] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)(mix64(seed + (uint64_t)g * 0x9E3779B97F4A7C15ull ^ mix64(local)) >> 32);
+    vals[i] = local;
+}
+__global__ void k_widen_u32(const uint32_t* __restrict__ in, int32_t N, int64_t* __restrict__ out) {
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = (int64_t)in[i];
 }
 
 struct Call {
@@ -114,21 +153,25 @@ struct Call {
     int64_t G; const int64_t* h_node_ptr; const int64_t* h_t;
     int o_v, o_n; const int64_t* d_perm; uint64_t seed;
     double* d_out; int64_t out_cap; int64_t* h_out_row_ptr; rlap_stats* st;
+    int symmetrize;
 };
 
-int run_once(rlap_handle h, const Call& c, int* retry_kind) {
-    *retry_kind = 0;
+// One attempt.  No host synchronisation until the single read-back at the end: every size is an upper bound
+// known on the host (E, N, G); what only the device knows (nnz, row counts, overflows, input checks) is read
+// by the kernels from device memory and reported once.
+int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need) {
+    *retry_kind = 0; *retry_need = 0;
     hipStream_t s = h->stream;
     const int64_t G = c.G, E = c.E;
     const int64_t N = c.h_node_ptr[G];
     if (c.h_node_ptr[0] != 0) return RLAP_E_BAD_ARG;
     for (int64_t g = 0; g < G; ++g) if (c.h_node_ptr[g + 1] < c.h_node_ptr[g]) return RLAP_E_BAD_ARG;
-    if (N >= (int64_t)1 << 30 || E >= (int64_t)1 << 31 || G >= (int64_t)1 << 30) return RLAP_E_TOO_LARGE;
+    const int64_t Eeff = c.symmetrize ? 2 * E : E;
+    if (N >= (int64_t)1 << 30 || Eeff >= (int64_t)1 << 31 || G >= (int64_t)1 << 30) return RLAP_E_TOO_LARGE;
     if (h->timing) HIPCHK(hipEventRecord(h->ev[0], s));
 
     rlap_stats st;
     std::memset(&st, 0, sizeof(st));
-    std::vector<int64_t> out_ptr_h((size_t)G + 1, 0);
 
     if (N == 0) {
         for (int64_t g = 0; g <= G; ++g) c.h_out_row_ptr[g] = 0;
@@ -136,94 +179,46 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         return RLAP_OK;
     }
 
-    // ---------------- setup: COO -> CSR ----------------
-    ENSURE(h->node_ptr_d, sizeof(int64_t) * (G + 1));
-    HIPCHK(hipMemcpyAsync(h->node_ptr_d.p, c.h_node_ptr, sizeof(int64_t) * (G + 1), hipMemcpyHostToDevice, s));
-    ENSURE(h->vgraph, sizeof(int32_t) * N);
-    hipLaunchKernelGGL(k_vertex_graph, dim3(nblk(N, 256)), dim3(256), 0, s, h->node_ptr_d.as<int64_t>(), (int)G, h->vgraph.as<int32_t>(), N);
-    ENSURE(h->flags, sizeof(int32_t) * FLAG_COUNT);
-    ENSURE(h->acc, sizeof(double) * 4);
-    ENSURE(h->counters, sizeof(unsigned long long) * 8);
-    HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int32_t) * FLAG_COUNT, s));
-    HIPCHK(hipMemsetAsync(h->acc.p, 0, sizeof(double) * 4, s));
-    HIPCHK(hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long) * 8, s));
-
-    int32_t nnz = 0;
-    const int64_t Ealloc = std::max<int64_t>(E, 1);
-    ENSURE(h->keys0, 8 * Ealloc); ENSURE(h->keys1, 8 * Ealloc);
-    ENSURE(h->idx0, 4 * Ealloc); ENSURE(h->idx1, 4 * Ealloc);
-    ENSURE(h->head, 4 * (Ealloc + 1)); ENSURE(h->pos, 4 * (Ealloc + 1));
-    if (E > 0) {
-        hipLaunchKernelGGL(k_edge_keys, dim3(nblk(E, 256)), dim3(256), 0, s, c.d_row, c.d_col, c.d_w, E, N, h->vgraph.as<int32_t>(),
-                           h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), h->flags.as<int32_t>());
-        int rc = sort_pairs(h, h->keys0.as<uint64_t>(), h->keys1.as<uint64_t>(), h->idx0.as<uint32_t>(), h->idx1.as<uint32_t>(), E, 0, 64);
-        if (rc) return rc;
-        HIPCHK(hipMemsetAsync(h->head.as<int32_t>() + E, 0, 4, s));
-        hipLaunchKernelGGL(k_heads, dim3(nblk(E, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), E, h->head.as<int32_t>());
-        rc = excl_scan(h, h->head.as<int32_t>(), h->pos.as<int32_t>(), E + 1);
-        if (rc) return rc;
-        int32_t flags_h[FLAG_COUNT];
-        HIPCHK(hipMemcpyAsync(&nnz, h->pos.as<int32_t>() + E, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(flags_h, h->flags.p, sizeof(flags_h), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (flags_h[FLAG_RANGE]) return RLAP_E_INDEX_RANGE;
-        if (flags_h[FLAG_CROSS]) return RLAP_E_BAD_ARG;
-    }
-    st.nnz = nnz;
-
-    // + what the workgroups may hold in reserve (one reservation each; the shape is chosen by graphs vs. CUs at launch)
-    const int64_t pool = (int64_t)(h->pool_factor * nnz) + 16 * N + 1024 + G * (G <= 512 ? (int64_t)POOL_GRAB_BIG : (int64_t)POOL_GRAB_SMALL);
-    const int64_t slot_cap = (int64_t)nnz + pool;
+    // ---------------- sizes (host-known upper bounds) ----------------
+    const int64_t nnz_ub = Eeff;
+    const double pool_factor = h->dbg_pool >= 0 ? h->dbg_pool : h->pool_factor;
+    const double log_factor = h->dbg_log >= 0 ? h->dbg_log : h->log_factor;
+    const int64_t pool = (int64_t)(pool_factor * nnz_ub) + (h->dbg_pool >= 0 ? 0 : 16 * N + 1024) + G * (G <= 512 ? (int64_t)POOL_GRAB_BIG : (int64_t)POOL_GRAB_SMALL);
+    const int64_t slot_cap = nnz_ub + pool;
     if (slot_cap >= ((int64_t)1 << 31) - 64) return RLAP_E_TOO_LARGE;
-    ENSURE(h->e_nbr, 4 * slot_cap); ENSURE(h->e_val, 8 * slot_cap); ENSURE(h->e_twin, 4 * slot_cap);
-    ENSURE(h->slot_col, 4 * std::max<int64_t>(nnz, 1));
-    ENSURE(h->deg, 4 * (N + 1)); ENSURE(h->colptr, 4 * (N + 1));
-    HIPCHK(hipMemsetAsync(h->deg.p, 0, 4 * (N + 1), s));
-    if (E > 0)
-        hipLaunchKernelGGL(k_fill_csr, dim3(nblk(E, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), h->idx1.as<uint32_t>(), h->head.as<int32_t>(),
-                           h->pos.as<int32_t>(), c.d_w, E, h->e_nbr.as<int32_t>(), h->e_val.as<double>(), h->slot_col.as<int32_t>(), h->deg.as<int32_t>());
-    { int rc = excl_scan(h, h->deg.as<int32_t>(), h->colptr.as<int32_t>(), N + 1); if (rc) return rc; }
-    if (nnz > 0)
-        hipLaunchKernelGGL(k_twin_sym, dim3(nblk(nnz, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
-                           h->slot_col.as<int32_t>(), nnz, h->e_twin.as<int32_t>(), h->acc.as<double>());
-    // per-graph nnz (colptr at graph boundaries) + symmetry verdict
-    ENSURE(h->gcol, 4 * (G + 1));
-    hipLaunchKernelGGL(k_gather_i32, dim3(nblk(G + 1, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->node_ptr_d.as<int64_t>(), (int32_t)(G + 1), h->gcol.as<int32_t>());
-    std::vector<int32_t> gcol_h((size_t)G + 1);
-    double acc_h[4];
-    HIPCHK(hipMemcpyAsync(gcol_h.data(), h->gcol.p, 4 * (G + 1), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(acc_h, h->acc.p, sizeof(acc_h), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (acc_h[2] != 0.0 || !(acc_h[0] <= 1e-24 * acc_h[1])) return RLAP_E_NOT_SYMMETRIC;
-
-    // ---------------- graph descriptors ----------------
     std::vector<GraphDesc> gd((size_t)G);
-    int64_t bucket_total = 0, log_total = 0, scr_total = 0, nelim_total = 0;
+    int64_t bucket_total = 0, nelim_total = 0;
     std::vector<int64_t> surv_base((size_t)G + 1, 0);
-    int64_t max_nnz_g = 0;
     for (int64_t g = 0; g < G; ++g) {
         GraphDesc& D = gd[g];
         std::memset(&D, 0, sizeof(D));
         int64_t n = c.h_node_ptr[g + 1] - c.h_node_ptr[g];
-        int64_t nnz_g = gcol_h[g + 1] - gcol_h[g];
-        max_nnz_g = std::max(max_nnz_g, nnz_g);
         D.vbase = (int32_t)c.h_node_ptr[g]; D.n = (int32_t)n; D.t = c.h_t[g];
         D.bucket_base = (int32_t)bucket_total; bucket_total += 2 * n + 1;
-        log_total += (int64_t)(h->log_factor * nnz_g) + (int64_t)BCH0 * (2 * n + 1) + 64;
-        int64_t sc = nnz_g / 2 + 8;
-        D.scr_base = (int32_t)scr_total; D.scr_cap = (int32_t)sc; scr_total += sc;
         int64_t ne = std::max<int64_t>(0, std::min<int64_t>(c.h_t[g], n - 1));
         D.n_elim = (int32_t)ne;
         nelim_total += ne;
         surv_base[g + 1] = surv_base[g] + (n - ne);
     }
-    if (bucket_total * BDIR >= ((int64_t)1 << 40) || bucket_total >= ((int64_t)1 << 31) || log_total >= ((int64_t)1 << 31) || scr_total >= ((int64_t)1 << 31)) return RLAP_E_TOO_LARGE;
+    const int64_t log_total = (int64_t)(log_factor * nnz_ub) + (h->dbg_log >= 0 ? 64 : (int64_t)BCH0 * bucket_total + 64 * G);
+    const int64_t scr_total = nnz_ub / 2 + 8 * G + 8;
+    if (bucket_total * BDIR >= ((int64_t)1 << 40) || bucket_total >= ((int64_t)1 << 31) || log_total >= ((int64_t)1 << 31)) return RLAP_E_TOO_LARGE;
     const int64_t S = surv_base[G];
     st.n_eliminated = nelim_total;
-    ENSURE(h->gd_d, sizeof(GraphDesc) * G);
-    HIPCHK(hipMemcpyAsync(h->gd_d.p, gd.data(), sizeof(GraphDesc) * G, hipMemcpyHostToDevice, s));
+    const int64_t scr_budget = h->dbg_scr >= 0 ? h->dbg_scr : h->scr_budget;
 
-    // ---------------- PQ init ----------------
+    // ---------------- workspace ----------------
+    ENSURE(h->node_ptr_d, sizeof(int64_t) * (G + 1));
+    ENSURE(h->vgraph, sizeof(int32_t) * N);
+    ENSURE(h->scal, sizeof(Scalars));
+    const int64_t Ealloc = std::max<int64_t>(Eeff, 1);
+    ENSURE(h->keys0, 8 * Ealloc); ENSURE(h->keys1, 8 * Ealloc);
+    ENSURE(h->idx0, 4 * Ealloc); ENSURE(h->idx1, 4 * Ealloc);
+    ENSURE(h->head, 4 * (Ealloc + 1)); ENSURE(h->pos, 4 * (Ealloc + 1));
+    ENSURE(h->e_nbr, 4 * slot_cap); ENSURE(h->e_val, 8 * slot_cap); ENSURE(h->e_twin, 4 * slot_cap);
+    ENSURE(h->slot_col, 4 * Ealloc);
+    ENSURE(h->deg, 4 * (N + 1)); ENSURE(h->colptr, 4 * (N + 1));
+    ENSURE(h->gd_d, sizeof(GraphDesc) * G);
     ENSURE(h->app_cnt, 4 * N); ENSURE(h->app_chunk, 4 * N); ENSURE(h->key, 4 * N); ENSURE(h->pqpos, 4 * N);
     ENSURE(h->origpos, 4 * N);
     ENSURE(h->ocur, 4 * bucket_total); ENSURE(h->oend, 4 * bucket_total);
@@ -231,28 +226,112 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     ENSURE(h->bs_v, 4 * log_total); ENSURE(h->bs_id, 4 * log_total); ENSURE(h->bs_pool_top, 4);
     ENSURE(h->batch_pos, 4 * N);
     ENSURE(h->skey0, 8 * N); ENSURE(h->skey1, 8 * N); ENSURE(h->sval0, 4 * N); ENSURE(h->sval1, 4 * N);
-    HIPCHK(hipMemsetAsync(h->bs_cnt.p, 0, 4 * bucket_total, s));
-    HIPCHK(hipMemsetAsync(h->bs_alloc.p, 0, 4 * bucket_total, s));
-    HIPCHK(hipMemsetAsync(h->bs_pool_top.p, 0, 4, s));
-    HIPCHK(hipMemsetAsync(h->batch_pos.p, 0xFF, 4 * N, s));
-    HIPCHK(hipMemsetAsync(h->ocur.p, 0, 4 * bucket_total, s));
-    HIPCHK(hipMemsetAsync(h->oend.p, 0, 4 * bucket_total, s));
+    ENSURE(h->orig_order, 4 * N);
+    ENSURE(h->scr_rec, sizeof(SRec) * scr_total); ENSURE(h->scr_i32, 4 * 10 * scr_total); ENSURE(h->scr_f64, 8 * 4 * scr_total);
+    ENSURE(h->pool_top, 4);
+    ENSURE(h->surv_base_d, 8 * (G + 1));
+    ENSURE(h->ext, 4 * (S + 1)); ENSURE(h->cnt, 4 * (S + 1)); ENSURE(h->tmp_off, 8 * (S + 1)); ENSURE(h->row_off, 8 * (S + 1));
+    ENSURE(h->tmp_nbr, 4 * slot_cap); ENSURE(h->tmp_val, 8 * slot_cap);   // staged rows: at most one per slot in use
+    ENSURE(h->sc_rec, sizeof(SRec) * scr_budget); ENSURE(h->sc_i32, 4 * 7 * scr_budget); ENSURE(h->sc_f64, 8 * 2 * scr_budget);
+    ENSURE(h->biglist, 4 * 6 * (S + 1));
+    ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
+    constexpr unsigned NHUGE = 32;
+    ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
+    ENSURE(h->out_ptr_d, 8 * (G + 1));
+    const size_t res_bytes = sizeof(CallResults) + 8 * (size_t)(G + 1);
+    ENSURE(h->results, res_bytes);
+    if (res_bytes > h->h_results_cap) {
+        if (h->h_results) (void)hipHostFree(h->h_results);
+        h->h_results = nullptr; h->h_results_cap = 0;
+        HIPCHK(hipHostMalloc(&h->h_results, res_bytes + 1024, hipHostMallocDefault));
+        h->h_results_cap = res_bytes + 1024;
+    }
+    {
+        // uniforms: a graph rarely draws more than its own directed entry count; an overflow doubles the table
+        int64_t guess = (G == 1) ? nnz_ub + 1024 : std::min<int64_t>(nnz_ub + 1024, 4 * (nnz_ub / G) + 65536);
+        guess = std::max(guess, h->rng_min);
+        int rc = ensure_rng(h, std::max<int64_t>(guess, h->rng_len)); if (rc) return rc;
+    }
+    // (test hook: the kernels are told the table is shorter than it is)
+    const int64_t rng_len_eff = h->dbg_rng >= 0 ? std::min<int64_t>(h->rng_len, h->dbg_rng) : h->rng_len;
+
+    Scalars* SC = h->scal.as<Scalars>();
+    int32_t* flags = SC->flags;
+    double* acc = SC->acc;
+    unsigned long long* counters = SC->counters;   // [0] sc scratch top, [1] live total
+    int32_t* nnz_p = &SC->nnz;
+
+    // ---------------- setup: COO -> CSR ----------------
+    HIPCHK(hipMemcpyAsync(h->node_ptr_d.p, c.h_node_ptr, sizeof(int64_t) * (G + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->gd_d.p, gd.data(), sizeof(GraphDesc) * G, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->surv_base_d.p, surv_base.data(), 8 * (G + 1), hipMemcpyHostToDevice, s));
+    {
+        Fills F;
+        F.add(h->scal.p, sizeof(Scalars) / 4, 0);
+        F.add(h->deg.p, N + 1, 0);
+        F.add(h->bs_cnt.p, bucket_total, 0); F.add(h->bs_alloc.p, bucket_total, 0);
+        F.add(h->ocur.p, bucket_total, 0); F.add(h->oend.p, bucket_total, 0);
+        F.add(h->bs_pool_top.p, 1, 0);
+        F.add(h->batch_pos.p, N, -1);
+        F.add(h->ext.as<int32_t>() + S, 1, 0); F.add(h->cnt.as<int32_t>() + S, 1, 0);
+        if (G == 1) F.add(h->vgraph.p, N, 0);
+        F.launch(s);
+    }
+    if (G > 1) hipLaunchKernelGGL(k_vertex_graph, dim3(nblk(N, 256)), dim3(256), 0, s, h->node_ptr_d.as<int64_t>(), (int)G, h->vgraph.as<int32_t>(), N);
+
+    if (Eeff > 0) {
+        hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_row, c.d_col, c.d_w, E, N, G > 1 ? h->vgraph.as<int32_t>() : (const int32_t*)nullptr,
+                           c.symmetrize, h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), flags);
+        // keys are (col << 32 | row) with ids < N, or all ones for dropped entries (these need the top bit to sort last)
+        int rc = sort_pairs(h, h->keys0.as<uint64_t>(), h->keys1.as<uint64_t>(), h->idx0.as<uint32_t>(), h->idx1.as<uint32_t>(), Eeff, 0, 64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_heads, dim3(nblk(Eeff + 1, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), Eeff, h->head.as<int32_t>());
+        rc = excl_scan(h, h->head.as<int32_t>(), h->pos.as<int32_t>(), Eeff + 1);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(nnz_p, h->pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), h->idx1.as<uint32_t>(), h->head.as<int32_t>(),
+                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
+                           h->slot_col.as<int32_t>(), h->deg.as<int32_t>());
+    }
+    { int rc = excl_scan(h, h->deg.as<int32_t>(), h->colptr.as<int32_t>(), N + 1); if (rc) return rc; }
+    if (Eeff > 0)
+        hipLaunchKernelGGL(k_twin_sym, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
+                           h->slot_col.as<int32_t>(), nnz_p, h->e_twin.as<int32_t>(), acc);
+    HIPCHK(hipMemcpyAsync(h->pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
+    // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)
+    hipLaunchKernelGGL(k_gd_scratch, dim3(1), dim3(256), 0, s, h->colptr.as<int32_t>(), h->node_ptr_d.as<int64_t>(), (int32_t)G, h->gd_d.as<GraphDesc>());
+
+    // ---------------- PQ init ----------------
+    const unsigned gbits = bits_for((uint64_t)(G > 0 ? G - 1 : 0));
     hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->vgraph.as<int32_t>(), (int32_t)N, h->key.as<int32_t>(),
                        h->pqpos.as<int32_t>(), h->app_cnt.as<int32_t>(), h->app_chunk.as<int32_t>(), h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
     {
-        int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 64);
+        // key = graph << 32 | degree: only the bits that can be set take part in the sort
+        int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 32 + gbits);
         if (rc) return rc;
     }
-    ENSURE(h->orig_order, 4 * N);
     HIPCHK(hipMemcpyAsync(h->orig_order.p, h->sval1.p, 4 * N, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, h->orig_order.as<uint32_t>(), h->key.as<int32_t>(), h->vgraph.as<int32_t>(),
                        h->gd_d.as<GraphDesc>(), (int32_t)N, h->ocur.as<int32_t>(), h->oend.as<int32_t>(), h->origpos.as<int32_t>());
 
-    { int rc = ensure_rng(h, std::max<int64_t>(max_nnz_g + 1024, h->rng_len)); if (rc) return rc; }
-
-    ENSURE(h->scr_rec, sizeof(SRec) * scr_total); ENSURE(h->scr_i32, 4 * 10 * scr_total); ENSURE(h->scr_f64, 8 * 4 * scr_total);
-    ENSURE(h->pool_top, 4);
-    HIPCHK(hipMemcpyAsync(h->pool_top.p, &nnz, 4, hipMemcpyHostToDevice, s));
+    // ---------------- o_v = random: the node_id vector ----------------
+    const int64_t* d_perm = c.d_perm;
+    if (c.o_v == OV_RANDOM) {
+        if (!d_perm) {
+            ENSURE(h->genperm, 8 * N);
+            hipLaunchKernelGGL(k_perm_keys, dim3(nblk(N, 256)), dim3(256), 0, s, h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N, c.seed,
+                               h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
+            int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 32 + gbits);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_widen_u32, dim3(nblk(N, 256)), dim3(256), 0, s, h->sval1.as<uint32_t>(), (int32_t)N, h->genperm.as<int64_t>());
+            d_perm = h->genperm.as<int64_t>();
+        } else {
+            ENSURE(h->permchk, 4 * N);
+            HIPCHK(hipMemsetAsync(h->permchk.p, 0, 4 * N, s));
+            hipLaunchKernelGGL(k_perm_check, dim3(nblk(N, 256)), dim3(256), 0, s, d_perm, h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N,
+                               h->permchk.as<int32_t>(), flags);
+        }
+    }
 
     Arrays A;
     A.colptr = h->colptr.as<int32_t>();
@@ -265,8 +344,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
     A.bs_cnt = h->bs_cnt.as<int32_t>(); A.bs_alloc = h->bs_alloc.as<int32_t>(); A.bs_dir = h->bs_dir.as<int32_t>();
     A.bs_v = h->bs_v.as<int32_t>(); A.bs_id = h->bs_id.as<int32_t>();
     A.bs_pool_top = h->bs_pool_top.as<int32_t>(); A.bs_pool_cap = (int32_t)log_total;
-    A.rng = h->rng.as<double>(); A.rng_len = h->rng_len;
-    A.perm = c.d_perm; A.o_v = c.o_v; A.o_n = c.o_n; A.shuffle_seed = c.seed;
+    A.rng = h->rng.as<double>(); A.rng_len = rng_len_eff;
+    A.perm = d_perm; A.o_v = c.o_v; A.o_n = c.o_n; A.shuffle_seed = c.seed;
     ElimScratch ES;
     ES.rec = h->scr_rec.as<SRec>(); ES.i32 = h->scr_i32.as<int32_t>(); ES.f64 = h->scr_f64.as<double>(); ES.cap = scr_total;
     ES.prof = nullptr;
@@ -279,11 +358,75 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
 
     if (h->timing) HIPCHK(hipEventRecord(h->ev[1], s));
     // ---------------- elimination ----------------
-    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>());
+    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, h->n_cu, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>(), flags, acc);
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
-    HIPCHK(hipMemcpyAsync(gd.data(), h->gd_d.p, sizeof(GraphDesc) * G, hipMemcpyDeviceToHost, s));
+
+    // ---------------- output ----------------
+    uint32_t* order = nullptr;
+    if (c.o_v == OV_RANDOM) {
+        hipLaunchKernelGGL(k_sc_perm_order, dim3(nblk(N, 256)), dim3(256), 0, s, d_perm, h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(),
+                           h->surv_base_d.as<int64_t>(), (int32_t)N, h->sval1.as<uint32_t>());
+        order = h->sval1.as<uint32_t>();
+    } else {
+        hipLaunchKernelGGL(k_sc_keys, dim3(nblk(N, 256)), dim3(256), 0, s, h->key.as<int32_t>(), h->pqpos.as<int32_t>(), h->origpos.as<int32_t>(),
+                           h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N, h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
+        // key = bucket << 32 | order, all ones for eliminated vertices
+        int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 64);
+        if (rc) return rc;
+        order = h->sval1.as<uint32_t>();
+    }
+    if (S > 0)
+        hipLaunchKernelGGL(k_sc_ext, dim3(nblk(S, 256)), dim3(256), 0, s, order, h->colptr.as<int32_t>(), h->app_cnt.as<int32_t>(), (int32_t)S, h->ext.as<int32_t>());
+    { int rc = excl_scan(h, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), S + 1); if (rc) return rc; }
+    ScScratch SS;
+    SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = scr_budget; SS.top = counters + 0; SS.flags = flags;
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
+    if (S > 0) {
+        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 6 ints: tiers 0..5
+        launch_sc_merge(s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
+                        h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1, h->biglist.as<int32_t>(), tiercounts);
+        HIPCHK(hipGetLastError());
+        // long columns: whole column in LDS, one single-wave workgroup each
+        int32_t* bigcount = tiercounts + 3;
+        int32_t* biglist_ptr = h->biglist.as<int32_t>() + 3 * (size_t)S;
+        if (!h->big_attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIGCAP * 16));
+            h->big_attr_set = true;
+        }
+        hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
+                           biglist_ptr, bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1,
+                           h->biglists.as<uint16_t>());
+        HIPCHK(hipGetLastError());
+        // longer than the LDS record array (hubs of weighted graphs): records in global scratch, a few workgroups
+        hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
+                           h->biglist.as<int32_t>() + 4 * (size_t)S, tiercounts + 4, h->tmp_nbr.as<int32_t>(),
+                           h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1, h->hugelists.as<uint16_t>(), SS.rec, SS.top, SS.cap, flags);
+        HIPCHK(hipGetLastError());
+    }
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[4], s));
+    { int rc = excl_scan(h, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), S + 1); if (rc) return rc; }
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[5], s));
+    if (S > 0 && c.out_cap > 0) {
+        const int64_t rows_ub = std::min<int64_t>(c.out_cap, slot_cap);
+        unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows_ub + 255) / 256, 256 * 8));
+        hipLaunchKernelGGL(k_sc_compact, dim3(grid), dim3(256), 0, s, order, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), h->tmp_off.as<int64_t>(),
+                           h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), (int32_t)S, c.d_out, c.out_cap);
+        HIPCHK(hipGetLastError());
+    }
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[6], s));
+    // ---------------- the one read-back ----------------
+    CallResults* res_d = h->results.as<CallResults>();
+    int64_t* out_ptr_d = reinterpret_cast<int64_t*>(res_d + 1);
+    hipLaunchKernelGGL(k_graph_rows, dim3(nblk(G + 1, 256)), dim3(256), 0, s, h->surv_base_d.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)G, out_ptr_d);
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, s, flags, acc, nnz_p, counters, h->tmp_off.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)S,
+                       h->gd_d.as<GraphDesc>(), (int32_t)G, h->pool_top.as<int32_t>(), h->bs_pool_top.as<int32_t>(), res_d);
+    HIPCHK(hipMemcpyAsync(h->h_results, h->results.p, res_bytes, hipMemcpyDeviceToHost, s));
+    if (h->timing) HIPCHK(hipEventRecord(h->ev[7], s));
     HIPCHK(hipStreamSynchronize(s));
+    const CallResults& R = *reinterpret_cast<const CallResults*>(h->h_results);
+    const int64_t* out_ptr_h = reinterpret_cast<const int64_t*>(reinterpret_cast<const CallResults*>(h->h_results) + 1);
+
     if (ES.prof) {
         long long pr[40];
         HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
@@ -293,109 +436,12 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         const char* wnames[9] = {"gather", "sort by id", "merge", "meta loads + order", "cumsum + recurrence", "sample", "replay + slots", "rewire", "pq commit"};
         for (int k = 0; k < 9; ++k) std::fprintf(stderr, "  single/wave: %-20s %10.3f ms\n", wnames[k], pr[24 + k] / 1e5);
     }
-    for (int64_t g = 0; g < G; ++g) {
-        if (gd[g].status) {
-            int stt = gd[g].status;
-            if (stt == ST_POOL_OVERFLOW) *retry_kind = 1;
-            else if (stt == ST_LOG_OVERFLOW) *retry_kind = 2;
-            else if (stt == ST_RNG_OVERFLOW) *retry_kind = 3;
-            return stt;
-        }
-        st.n_draws = std::max<int64_t>(st.n_draws, gd[g].n_draws);
-    }
 
-    // ---------------- output ----------------
-    ENSURE(h->surv_base_d, 8 * (G + 1));
-    HIPCHK(hipMemcpyAsync(h->surv_base_d.p, surv_base.data(), 8 * (G + 1), hipMemcpyHostToDevice, s));
-    uint32_t* order = nullptr;
-    if (c.o_v == OV_RANDOM) {
-        hipLaunchKernelGGL(k_sc_perm_order, dim3(nblk(N, 256)), dim3(256), 0, s, c.d_perm, h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(),
-                           h->surv_base_d.as<int64_t>(), (int32_t)N, h->sval1.as<uint32_t>());
-        order = h->sval1.as<uint32_t>();
-    } else {
-        hipLaunchKernelGGL(k_sc_keys, dim3(nblk(N, 256)), dim3(256), 0, s, h->key.as<int32_t>(), h->pqpos.as<int32_t>(), h->origpos.as<int32_t>(),
-                           h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N, h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
-        int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 64);
-        if (rc) return rc;
-        order = h->sval1.as<uint32_t>();
-    }
-    ENSURE(h->ext, 4 * (S + 1)); ENSURE(h->cnt, 4 * (S + 1)); ENSURE(h->tmp_off, 8 * (S + 1)); ENSURE(h->row_off, 8 * (S + 1));
-    HIPCHK(hipMemsetAsync(h->ext.as<int32_t>() + S, 0, 4, s));
-    HIPCHK(hipMemsetAsync(h->cnt.as<int32_t>() + S, 0, 4, s));
-    unsigned long long* counters = h->counters.as<unsigned long long>();  // [0] sc scratch top, [1] live total, [2] big extent total
-    if (S > 0) {
-        hipLaunchKernelGGL(k_sc_ext, dim3(nblk(S, 256)), dim3(256), 0, s, order, h->colptr.as<int32_t>(), h->app_cnt.as<int32_t>(), (int32_t)S, h->ext.as<int32_t>());
-        hipLaunchKernelGGL(k_ext_totals, dim3(nblk(S, 256)), dim3(256), 0, s, h->ext.as<int32_t>(), (int32_t)S, (int32_t)SCAP, counters + 2);
-    }
-    { int rc = excl_scan(h, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), S + 1); if (rc) return rc; }
-    int64_t ext_total = 0;
-    unsigned long long big_total = 0;
-    HIPCHK(hipMemcpyAsync(&ext_total, h->tmp_off.as<int64_t>() + S, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&big_total, counters + 2, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    ENSURE(h->tmp_nbr, 4 * std::max<int64_t>(ext_total, 1)); ENSURE(h->tmp_val, 8 * std::max<int64_t>(ext_total, 1));
-    const int64_t bigcap = (int64_t)big_total + 8;
-    ENSURE(h->sc_rec, sizeof(SRec) * bigcap); ENSURE(h->sc_i32, 4 * 7 * bigcap); ENSURE(h->sc_f64, 8 * 2 * bigcap);
-    ScScratch SS;
-    SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = bigcap; SS.top = counters + 0;
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
-    if (S > 0) {
-        ENSURE(h->biglist, 4 * 6 * (S + 1));
-        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 6 ints: tiers 0..5
-        launch_sc_merge(s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
-                        h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1, h->biglist.as<int32_t>(), tiercounts);
-        HIPCHK(hipGetLastError());
-    }
-    if (S > 0) {
-        // long columns: whole column in LDS, one single-wave workgroup each
-        int32_t* bigcount = reinterpret_cast<int32_t*>(counters + 4) + 3;
-        int32_t* biglist_ptr = h->biglist.as<int32_t>() + 3 * (size_t)S;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIGCAP * 16));
-            attr_set = true;
-        }
-        ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
-        hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s, A, order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
-                           biglist_ptr, bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1,
-                           h->biglists.as<uint16_t>());
-        HIPCHK(hipGetLastError());
-        // longer than the LDS record array (hubs of weighted graphs): records in global scratch, a few workgroups
-        constexpr unsigned NHUGE = 32;
-        ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
-        hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s, A, order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
-                           h->biglist.as<int32_t>() + 4 * (size_t)S, reinterpret_cast<int32_t*>(counters + 4) + 4, h->tmp_nbr.as<int32_t>(),
-                           h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1, h->hugelists.as<uint16_t>(), SS.rec, SS.top);
-        HIPCHK(hipGetLastError());
-    }
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[4], s));
-    { int rc = excl_scan(h, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), S + 1); if (rc) return rc; }
-    int64_t m_total = 0;
-    unsigned long long live_total = 0;
-    HIPCHK(hipMemcpyAsync(&m_total, h->row_off.as<int64_t>() + S, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&live_total, counters + 1, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    st.out_rows = m_total;
-    st.live_entries = (int64_t)live_total;
-    if (m_total > c.out_cap) {
-        c.h_out_row_ptr[G] = m_total;
-        if (c.st) *c.st = st;
-        return RLAP_E_OUT_OVERFLOW;
-    }
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[5], s));
-    if (S > 0 && m_total > 0) {
-        unsigned grid = (unsigned)std::min<int64_t>((m_total + 255) / 256, 256 * 8);
-        hipLaunchKernelGGL(k_sc_compact, dim3(grid), dim3(256), 0, s, order, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), h->tmp_off.as<int64_t>(),
-                           h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), (int32_t)S, c.d_out);
-        HIPCHK(hipGetLastError());
-    }
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[6], s));
-    ENSURE(h->out_ptr_d, 8 * (G + 1));
-    hipLaunchKernelGGL(k_graph_rows, dim3(nblk(G + 1, 256)), dim3(256), 0, s, h->surv_base_d.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)G, h->out_ptr_d.as<int64_t>());
-    HIPCHK(hipMemcpyAsync(out_ptr_h.data(), h->out_ptr_d.p, 8 * (G + 1), hipMemcpyDeviceToHost, s));
-    if (h->timing) HIPCHK(hipEventRecord(h->ev[7], s));
-    HIPCHK(hipStreamSynchronize(s));
-    for (int64_t g = 0; g <= G; ++g) c.h_out_row_ptr[g] = out_ptr_h[g];
+    st.nnz = R.nnz;
+    st.n_draws = R.n_draws;
+    st.n_rounds = R.rounds; st.n_singles = R.singles;
+    st.out_rows = R.m_total;
+    st.live_entries = R.live_total;
     if (h->timing) {
         float t = 0;
         (void)hipEventElapsedTime(&t, h->ev[0], h->ev[1]); st.ms_setup = t;
@@ -406,7 +452,47 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind) {
         (void)hipEventElapsedTime(&t, h->ev[0], h->ev[7]); st.ms_total = t;
     }
     if (c.st) *c.st = st;
+    // input errors first (the elimination was skipped), then growth limits (the call is repeated), then the output size
+    if (R.status == ST_INDEX_RANGE || R.flags[FLAG_RANGE]) return RLAP_E_INDEX_RANGE;
+    if (R.status == ST_BAD_ARG || R.flags[FLAG_CROSS] || R.flags[FLAG_PERM]) return RLAP_E_BAD_ARG;
+    if (R.status == ST_NOT_SYMMETRIC) return RLAP_E_NOT_SYMMETRIC;
+    if (R.status) {
+        if (R.status == ST_POOL_OVERFLOW) *retry_kind = 1;
+        else if (R.status == ST_LOG_OVERFLOW) *retry_kind = 2;
+        else if (R.status == ST_RNG_OVERFLOW) *retry_kind = 3;
+        return R.status;
+    }
+    if (R.flags[FLAG_SCR]) { *retry_kind = 4; *retry_need = R.scr_need; return RLAP_E_INTERNAL; }
+    for (int64_t g = 0; g <= G; ++g) c.h_out_row_ptr[g] = out_ptr_h[g];
+    if (R.m_total > c.out_cap) { c.h_out_row_ptr[G] = R.m_total; return RLAP_E_OUT_OVERFLOW; }
     return RLAP_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1; bool changed = false;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = (hipSetDevice(dev) == hipSuccess); }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+
+int run_call(rlap_handle h, const Call& c) {
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device);
+    int rc = RLAP_E_INTERNAL;
+    int retries = 0;
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        int kind = 0; int64_t need = 0;
+        rc = run_once(h, c, &kind, &need);
+        if (kind == 0) break;
+        ++retries;
+        // a test hook's tiny limit applies to the first attempt only; afterwards the regular growth takes over
+        if (kind == 1) { if (h->dbg_pool >= 0) h->dbg_pool = -1.0; else h->pool_factor = h->pool_factor * 2 + 1; }
+        else if (kind == 2) { if (h->dbg_log >= 0) h->dbg_log = -1.0; else h->log_factor *= 2; }
+        else if (kind == 3) { if (h->dbg_rng >= 0) h->dbg_rng = -1; else h->rng_min = std::max<int64_t>(2 * h->rng_len, 1 << 16); }
+        else if (kind == 4) { if (h->dbg_scr >= 0) h->dbg_scr = -1; h->scr_budget = std::max<int64_t>(h->scr_budget, need + 8); }
+    }
+    h->total_retries += retries;
+    if (c.st) c.st->n_retries = retries;
+    return rc;
 }
 
 }  // namespace
@@ -419,6 +505,7 @@ int rlap_create(rlap_handle* out) {
     HIPCHK(hipGetDevice(&dev));
     rlap_handle h = new rlap_handle_s();
     h->device = dev;
+    if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
     for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
     *out = h;
     return RLAP_OK;
@@ -426,11 +513,13 @@ int rlap_create(rlap_handle* out) {
 
 int rlap_destroy(rlap_handle h) {
     if (!h) return RLAP_OK;
-    DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->flags, &h->acc, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
-                      &h->deg, &h->colptr, &h->slot_col, &h->gcol, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
+    DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->scal, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
+                      &h->deg, &h->colptr, &h->slot_col, &h->permchk, &h->genperm, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
                       &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
-                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->counters, &h->biglist, &h->biglists, &h->hugelists};
+                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->biglist, &h->biglists, &h->hugelists, &h->results};
+    DeviceGuard dg(h->device);
+    if (h->h_results) (void)hipHostFree(h->h_results);
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     delete h;
@@ -489,20 +578,10 @@ int rlap_approx_chol_batched(rlap_handle h, const int64_t* d_row, const int64_t*
                              uint64_t shuffle_seed, double* d_out, int64_t out_cap_rows, int64_t* h_out_row_ptr, rlap_stats* h_stats) {
     if (!h || G < 1 || E < 0 || !h_node_ptr || !h_num_remove || !h_out_row_ptr) return RLAP_E_BAD_ARG;
     if (o_v < 0 || o_v > 2 || o_n < 0 || o_n > 2) return RLAP_E_BAD_ARG;
-    if (o_v == RLAP_OV_RANDOM && !d_perm && h_node_ptr[G] > 0) return RLAP_E_BAD_ARG;
     if (E > 0 && (!d_row || !d_col)) return RLAP_E_BAD_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    Call c{d_row, d_col, d_w, E, G, h_node_ptr, h_num_remove, o_v, o_n, d_perm, shuffle_seed, d_out, out_cap_rows, h_out_row_ptr, h_stats};
-    int rc = RLAP_E_INTERNAL;
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        int kind = 0;
-        rc = run_once(h, c, &kind);
-        if (kind == 1) { h->pool_factor = h->pool_factor * 2 + 1; continue; }
-        if (kind == 2) { h->log_factor *= 2; continue; }
-        if (kind == 3) { int r2 = ensure_rng(h, h->rng_len * 2); if (r2) return r2; continue; }
-        break;
-    }
-    return rc;
+    if (out_cap_rows > 0 && !d_out) return RLAP_E_BAD_ARG;
+    Call c{d_row, d_col, d_w, E, G, h_node_ptr, h_num_remove, o_v, o_n, d_perm, shuffle_seed, d_out, out_cap_rows, h_out_row_ptr, h_stats, 0};
+    return run_call(h, c);
 }
 
 int rlap_approx_chol(rlap_handle h, const int64_t* d_row, const int64_t* d_col, const double* d_w, int64_t E, int64_t n, int64_t t,
@@ -517,8 +596,51 @@ int rlap_approx_chol(rlap_handle h, const int64_t* d_row, const int64_t* d_col, 
     return rc;
 }
 
+int rlap_approx_chol_from_edges(rlap_handle h, const int64_t* d_src, const int64_t* d_dst, const double* d_w, int64_t E, int64_t n, int64_t t,
+                                double remove_frac, int symmetrize, int o_v, int o_n, const int64_t* d_perm, uint64_t shuffle_seed,
+                                double* d_out, int64_t out_cap_rows, int64_t* h_out_rows, int64_t* h_num_nodes, rlap_stats* h_stats) {
+    if (!h || E < 0 || !h_out_rows) return RLAP_E_BAD_ARG;
+    if (o_v < 0 || o_v > 2 || o_n < 0 || o_n > 2) return RLAP_E_BAD_ARG;
+    if (E > 0 && (!d_src || !d_dst)) return RLAP_E_BAD_ARG;
+    if (out_cap_rows > 0 && !d_out) return RLAP_E_BAD_ARG;
+    if (n < 0 && d_perm) return RLAP_E_BAD_ARG;   // an injected node_id vector needs a known num_nodes
+    if (n < 0) {
+        // num_nodes = edge_index.max() + 1 (augmentor_benchmarks.py:77): one reduction + one 8-byte read-back
+        std::lock_guard<std::mutex> lock(h->mu);
+        DeviceGuard dg(h->device);
+        unsigned long long mx = 0;
+        if (E > 0) {
+            ENSURE(h->scal, sizeof(Scalars));
+            unsigned long long* d_mx = &h->scal.as<Scalars>()->maxid;
+            HIPCHK(hipMemsetAsync(d_mx, 0, 8, h->stream));
+            hipLaunchKernelGGL(k_max_id, dim3((unsigned)std::min<int64_t>((E + 255) / 256, 1024)), dim3(256), 0, h->stream, d_src, d_dst, E, d_mx);
+            HIPCHK(hipMemcpyAsync(&mx, d_mx, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        n = (int64_t)mx;
+    }
+    if (t < 0) t = (int64_t)(remove_frac * (double)n);   // int(frac * num_nodes), augmentor_benchmarks.py:78
+    if (h_num_nodes) *h_num_nodes = n;
+    int64_t node_ptr[2] = {0, n};
+    int64_t tt[1] = {t};
+    int64_t rp[2] = {0, 0};
+    Call c{d_src, d_dst, d_w, E, 1, node_ptr, tt, o_v, o_n, d_perm, shuffle_seed, d_out, out_cap_rows, rp, h_stats, symmetrize ? 1 : 0};
+    int rc = run_call(h, c);
+    *h_out_rows = rp[1];
+    return rc;
+}
+
+int rlap_debug_set_limits(rlap_handle h, double pool_factor, double log_factor, int64_t rng_len, int64_t scratch_entries) {
+    if (!h) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->dbg_pool = pool_factor; h->dbg_log = log_factor; h->dbg_rng = rng_len; h->dbg_scr = scratch_entries;
+    return RLAP_OK;
+}
+
 int rlap_rng_uniforms(rlap_handle h, int64_t count, double* d_out) {
     if (!h || count < 0) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device);
     int rc = ensure_rng(h, count);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(d_out, h->rng.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));

@@ -42,6 +42,9 @@ enum {
 // Keyed neighbour order: replaces std::shuffle(std::random_device) of
 // preconditioner.cc:303-307,340-342 by an injected, reproducible order
 // (ascending (key, nbr)).  Same definition in oracle/rlap_oracle.cc.
+// `vertex` and `nbr` are ids LOCAL to their graph (global id - GraphDesc::vbase) and graph g of a
+// batch uses the seed `shuffle_seed + g`, so that a batched call returns what separate calls on the
+// single graphs return (include/rlap_hip.h).
 // ---------------------------------------------------------------------------
 RLAP_HD uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
@@ -497,10 +500,11 @@ RLAP_HD int32_t serial_sort_merge(const Arrays& A, const GraphDesc& G, const Col
 }
 
 // Order the m merged neighbours by o_n (:295-307) into B.a_*; B.t_of[j] = merged index.
-RLAP_HD void serial_order(const Arrays& A, const ColBuf& B, int32_t m, int32_t vertex, int phase) {
+// `vertex` and B.b_nbr are global ids of the graph starting at `vbase`; A.shuffle_seed is that graph's seed.
+RLAP_HD void serial_order(const Arrays& A, const ColBuf& B, int32_t m, int32_t vertex, int phase, int32_t vbase) {
     if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
-        uint64_t base = keyed_order_base(A.shuffle_seed, vertex, phase);
-        for (int32_t i = 0; i < m; ++i) { B.rec[i].key = keyed_order_dkey(base, B.b_nbr[i]); B.rec[i].idx = i; B.rec[i].aux = 0; }
+        uint64_t base = keyed_order_base(A.shuffle_seed, vertex - vbase, phase);
+        for (int32_t i = 0; i < m; ++i) { B.rec[i].key = keyed_order_dkey(base, B.b_nbr[i] - vbase); B.rec[i].idx = i; B.rec[i].aux = 0; }
         std_sort_emul<false>(B.rec, m);
     } else {
         for (int32_t i = 0; i < m; ++i) { B.rec[i].key = B.b_val[i]; B.rec[i].idx = i; B.rec[i].aux = 0; }
@@ -538,7 +542,7 @@ RLAP_HD int serial_eliminate(const Arrays& A, GraphDesc& G, const ColBuf& B, int
     int32_t len0 = serial_gather(A, v, B, cap);
     if (len0 > cap) return ST_INTERNAL;
     int32_t m = serial_sort_merge(A, G, B, len0, true, use_pq);
-    serial_order(A, B, m, v, 0);
+    serial_order(A, B, m, v, 0, G.vbase);
     if (A.o_v == OV_COARSEN) {
         if (m >= 1) {
             double csum = 0;
@@ -601,7 +605,7 @@ RLAP_HD int32_t serial_output(const Arrays& A, const GraphDesc& G, const ColBuf&
     if (len0 > cap) return -1;
     int32_t m = serial_sort_merge(A, G, B, len0, false, false);
     if (count_only) return m;
-    serial_order(A, B, m, v, 1);
+    serial_order(A, B, m, v, 1, G.vbase);
     for (int32_t j = 0; j < m; ++j) {
         double* o = out + 3 * (row0 + j);
         o[0] = (double)B.a_nbr[j]; o[1] = (double)v; o[2] = B.a_val[j];
@@ -740,7 +744,7 @@ RLAP_HD void cand_load(const Arrays& A, CT& C, int32_t e) {
 }
 // drop dead entries -> sort by id (:275) -> multi-edges go to the single-vertex path -> order by o_n (:295-307)
 template <class CT>
-RLAP_HD void cand_finish(const Arrays& A, CT& C) {
+RLAP_HD void cand_finish(const Arrays& A, CT& C, int32_t vbase = 0) {
     if (C.flags & CF_BIG) return;
     int32_t len = 0;
     for (int32_t e = 0; e < C.ext; ++e) {
@@ -765,8 +769,8 @@ RLAP_HD void cand_finish(const Arrays& A, CT& C) {
         for (int32_t i = 1; i < len; ++i) if (C.e[i].nbr == C.e[i - 1].nbr) { C.flags = CF_DUP; return; }
     }
     if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
-        uint64_t kb = keyed_order_base(A.shuffle_seed, C.v, 0);
-        for (int32_t i = 0; i < len; ++i) C.e[i].aux = keyed_order_dkey(kb, C.e[i].nbr);
+        uint64_t kb = keyed_order_base(A.shuffle_seed, C.v - vbase, 0);
+        for (int32_t i = 0; i < len; ++i) C.e[i].aux = keyed_order_dkey(kb, C.e[i].nbr - vbase);
         gs_std_sort<Ent>(C.e, len, EntLessAux());
     } else if (A.o_n == ON_ASC) {
         gs_std_sort<Ent>(C.e, len, EntLessVal());
@@ -776,10 +780,10 @@ RLAP_HD void cand_finish(const Arrays& A, CT& C) {
     C.ndraw = (A.o_v == OV_COARSEN) ? (len >= 1 ? 1 : 0) : (len > 1 ? len - 1 : 0);
 }
 template <class CT>
-RLAP_HD void cand_prepare(const Arrays& A, int32_t v, CT& C) {
+RLAP_HD void cand_prepare(const Arrays& A, int32_t v, CT& C, int32_t vbase = 0) {
     cand_meta(A, v, C);
     for (int32_t e = 0; e < C.ext; ++e) cand_load(A, C, e);
-    cand_finish(A, C);
+    cand_finish(A, C, vbase);
 }
 
 RLAP_HD int32_t ent_upper_index(const Ent* e, int32_t m, double r) {  // first a with cum[a] > r, else m-1

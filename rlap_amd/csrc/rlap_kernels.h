@@ -7,7 +7,20 @@
 
 namespace rlap {
 
-enum { FLAG_RANGE = 0, FLAG_CROSS = 1, FLAG_COUNT = 4 };
+enum { FLAG_RANGE = 0, FLAG_CROSS = 1, FLAG_PERM = 2, FLAG_SCR = 3, FLAG_COUNT = 4 };
+
+// several (pointer, count, value) fills done by one launch
+struct FillJobs { int32_t* ptr[16]; int64_t count[16]; int32_t value[16]; int n; };
+
+// what the host reads back, once, at the end of a call
+struct CallResults {
+    int32_t flags[FLAG_COUNT];
+    double acc[4];
+    int32_t nnz, status;
+    int64_t n_draws, rounds, singles;
+    int64_t live_total, scr_need, ext_total, m_total;
+    int32_t pool_used, log_used;
+};
 constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
 constexpr int SCAP = 512;  // output pass: same
 constexpr int BIGCAP = 8192;  // output pass, long columns: one workgroup with a 128 KB LDS record array
@@ -39,6 +52,7 @@ struct ScScratch {
     double* f64;    // 2 arrays (a_val,b_val)
     int64_t cap;
     unsigned long long* top;
+    int32_t* flags;   // FLAG_SCR is raised when `cap` entries do not suffice
     __host__ __device__ ColBuf colbuf(int64_t base) const {
         ColBuf B;
         B.rec = rec + base;
@@ -56,18 +70,25 @@ __global__ void k_transpose_copy(const double* in, double* out, int64_t rows, in
 __global__ void k_unpack_edge_info(const double* ei, int64_t E, int64_t* row, int64_t* col, double* w);
 __global__ void k_vertex_graph(const int64_t* node_ptr, int G, int32_t* vgraph, int64_t N);
 __global__ void k_edge_keys(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t N, const int32_t* vgraph,
-                            uint64_t* keys, uint32_t* idx, int32_t* flags);
+                            int symmetrize, uint64_t* keys, uint32_t* idx, int32_t* flags);
+__global__ void k_max_id(const int64_t* row, const int64_t* col, int64_t E, unsigned long long* out);
+__global__ void k_fill_multi(FillJobs J);
+__global__ void k_perm_check(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, int32_t N, int32_t* seen, int32_t* flags);
+__global__ void k_gd_scratch(const int32_t* colptr, const int64_t* node_ptr, int32_t G, GraphDesc* gd);
+__global__ void k_collect(const int32_t* flags, const double* acc, const int32_t* nnz_p, const unsigned long long* counters,
+                          const int64_t* tmp_off, const int64_t* row_off, int32_t S, const GraphDesc* gd, int32_t G,
+                          const int32_t* pool_top, const int32_t* bs_pool_top, CallResults* out);
 __global__ void k_heads(const uint64_t* keys, int64_t E, int32_t* head);
 __global__ void k_fill_csr(const uint64_t* keys, const uint32_t* idx, const int32_t* head, const int32_t* pos, const double* w,
-                           int64_t E, int32_t* e_nbr, double* e_val, int32_t* slot_col, int32_t* deg);
-__global__ void k_twin_sym(const int32_t* colptr, const int32_t* e_nbr, const double* e_val, const int32_t* slot_col, int32_t nnz,
+                           int64_t E, int set_semantics, int32_t* e_nbr, double* e_val, int32_t* slot_col, int32_t* deg);
+__global__ void k_twin_sym(const int32_t* colptr, const int32_t* e_nbr, const double* e_val, const int32_t* slot_col, const int32_t* nnz_p,
                            int32_t* e_twin, double* acc);
 __global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, int32_t* key, int32_t* pqpos, int32_t* app_cnt,
                           int32_t* app_chunk, uint64_t* skey, uint32_t* sval);
 __global__ void k_bucket_bounds(const uint32_t* order, const int32_t* key, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
                                 int32_t* ocur, int32_t* oend, int32_t* origpos);
-void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
-                            int32_t* batch_pos);
+void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
+                            int32_t* batch_pos, const int32_t* flags, const double* acc);
 __global__ void k_sc_keys(const int32_t* key, const int32_t* pqpos, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,
                           int32_t N, uint64_t* skey, uint32_t* sval);
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,
@@ -77,13 +98,13 @@ void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, c
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
                      unsigned long long* live_total, int32_t* lists, int32_t* counts);
 __global__ void k_debug_wave_sort(const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out);
-__global__ void k_sc_merge_big(Arrays A, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
+__global__ void k_sc_merge_big(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
                                int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists);
-__global__ void k_sc_merge_huge(Arrays A, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
+__global__ void k_sc_merge_huge(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
                                 int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists, SRec* scratch,
-                                unsigned long long* scratch_top);
+                                unsigned long long* scratch_top, int64_t scratch_cap, int32_t* flags);
 __global__ void k_sc_compact(const uint32_t* order, const int32_t* cnt, const int64_t* row_off, const int64_t* tmp_off,
-                             const int32_t* tmp_nbr, const double* tmp_val, int32_t S, double* out);
+                             const int32_t* tmp_nbr, const double* tmp_val, int32_t S, double* out, int64_t out_cap);
 __global__ void k_graph_rows(const int64_t* surv_base, const int64_t* row_off, int32_t G, int64_t* out_ptr);
 
 }  // namespace rlap

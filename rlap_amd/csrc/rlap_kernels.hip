@@ -112,40 +112,142 @@ __global__ void k_vertex_graph(const int64_t* __restrict__ node_ptr, int G, int3
     vgraph[v] = lo;
 }
 
+// symmetrize != 0: the step before the path (PyG to_undirected, scripts/node_shared.py:326-327) fused in -- every
+// input entry (a,b) also yields (b,a); the duplicates this creates are folded by k_heads / k_fill_csr.
 __global__ void k_edge_keys(const int64_t* __restrict__ row, const int64_t* __restrict__ col, const double* __restrict__ w,
-                            int64_t E, int64_t N, const int32_t* __restrict__ vgraph, uint64_t* __restrict__ keys,
+                            int64_t E, int64_t N, const int32_t* __restrict__ vgraph, int symmetrize, uint64_t* __restrict__ keys,
                             uint32_t* __restrict__ idx, int32_t* __restrict__ flags) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= E) return;
-    int64_t r = row[p], c = col[p];
-    double wv = w ? w[p] : 1.0;
+    const int64_t Eeff = symmetrize ? 2 * E : E;
+    if (p >= Eeff) return;
+    const int64_t q = p < E ? p : p - E;
+    int64_t r = row[q], c = col[q];
+    if (p >= E) { const int64_t t = r; r = c; c = t; }
+    double wv = w ? w[q] : 1.0;
     uint64_t k = ~0ull;
     if (r < 0 || r >= N || c < 0 || c >= N) {
         flags[FLAG_RANGE] = 1;
     } else if (wv != 0) {
-        if (vgraph[r] != vgraph[c]) flags[FLAG_CROSS] = 1;
+        if (vgraph && vgraph[r] != vgraph[c]) flags[FLAG_CROSS] = 1;
         k = ((uint64_t)c << 32) | (uint64_t)r;
     }
     keys[p] = k;
-    idx[p] = (uint32_t)p;
+    idx[p] = (uint32_t)q;
+}
+
+// num_nodes = edge_index.max() + 1 (scripts/augmentor_benchmarks.py:77) without a torch reduction + .item()
+__global__ void k_max_id(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t E, unsigned long long* __restrict__ out) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    long long m = -1;
+    for (; p < E; p += (int64_t)gridDim.x * blockDim.x) { long long r = row[p], c = col[p]; m = r > m ? r : m; m = c > m ? c : m; }
+    for (int off = 32; off > 0; off >>= 1) { long long o = __shfl_down(m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(out, (unsigned long long)(m + 1));
+}
+
+// several small fills in one launch (per-call state that used to take a dozen memsets)
+__global__ void k_fill_multi(FillJobs J) {
+    const int j = blockIdx.y;
+    if (j >= J.n) return;
+    int32_t* p = J.ptr[j];
+    const int64_t cnt = J.count[j];
+    const int32_t v = J.value[j];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// o_v = random: the injected node_id vector must hold, per graph, a permutation of its LOCAL ids
+// (preconditioner.cc:588-601 builds 0..n-1 and shuffles it); anything else would index out of bounds.
+__global__ void k_perm_check(const int64_t* __restrict__ perm, const int32_t* __restrict__ vgraph, const GraphDesc* __restrict__ gd,
+                             int32_t N, int32_t* __restrict__ seen, int32_t* __restrict__ flags) {
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const GraphDesc& D = gd[vgraph[i]];
+    const int64_t p = perm[i];
+    if (p < 0 || p >= (int64_t)D.n) { flags[FLAG_PERM] = 1; return; }
+    if (atomicExch(&seen[D.vbase + (int32_t)p], 1) != 0) flags[FLAG_PERM] = 1;
+}
+
+// per-graph scratch for the long-column fall-backs: nnz_g / 2 + 8 entries each, bases by a running sum
+// (one workgroup; the per-graph nnz is only known on the device)
+__global__ __launch_bounds__(256) void k_gd_scratch(const int32_t* __restrict__ colptr, const int64_t* __restrict__ node_ptr, int32_t G,
+                                                    GraphDesc* __restrict__ gd) {
+    __shared__ int32_t s_w[4];
+    __shared__ int32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int32_t g0 = 0; g0 < G; g0 += 256) {
+        const int32_t g = g0 + tid;
+        int32_t sc = 0;
+        if (g < G) sc = (colptr[node_ptr[g + 1]] - colptr[node_ptr[g]]) / 2 + 8;
+        int32_t incl = sc;
+        for (int off = 1; off < 64; off <<= 1) { int32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        int32_t base = s_carry;
+        for (int w = 0; w < wv; ++w) base += s_w[w];
+        if (g < G) { gd[g].scr_base = base + incl - sc; gd[g].scr_cap = sc; }
+        __syncthreads();
+        if (tid == 255) s_carry = base + incl;
+        __syncthreads();
+    }
+}
+
+// everything the host wants to know about a call, gathered into one block (one D2H copy at the end)
+__global__ __launch_bounds__(256) void k_collect(const int32_t* __restrict__ flags, const double* __restrict__ acc, const int32_t* __restrict__ nnz_p,
+                          const unsigned long long* __restrict__ counters, const int64_t* __restrict__ tmp_off, const int64_t* __restrict__ row_off,
+                          int32_t S, const GraphDesc* __restrict__ gd, int32_t G, const int32_t* __restrict__ pool_top,
+                          const int32_t* __restrict__ bs_pool_top, CallResults* __restrict__ out) {
+    __shared__ int32_t s_st;
+    __shared__ unsigned long long s_nd, s_rounds, s_singles;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_st = 0; s_nd = 0ull; s_rounds = 0ull; s_singles = 0ull; }
+    __syncthreads();
+    int32_t st = 0; unsigned long long nd = 0, rounds = 0, singles = 0;
+    for (int32_t g = tid; g < G; g += blockDim.x) {
+        const int32_t sg = gd[g].status;
+        if (sg > st) st = sg;
+        const unsigned long long d = (unsigned long long)gd[g].n_draws;
+        nd = d > nd ? d : nd;
+        rounds += (unsigned long long)gd[g].pad0; singles += (unsigned long long)gd[g].pad1;
+    }
+    if (st) atomicMax(&s_st, st);
+    if (nd) atomicMax(&s_nd, nd);
+    if (rounds) atomicAdd(&s_rounds, rounds);
+    if (singles) atomicAdd(&s_singles, singles);
+    __syncthreads();
+    if (tid != 0) return;
+    CallResults R;
+    for (int q = 0; q < FLAG_COUNT; ++q) R.flags[q] = flags[q];
+    for (int q = 0; q < 4; ++q) R.acc[q] = acc[q];
+    R.nnz = *nnz_p;
+    R.live_total = (int64_t)counters[1];
+    R.scr_need = (int64_t)counters[0];
+    R.ext_total = tmp_off[S];
+    R.m_total = row_off[S];
+    R.pool_used = *pool_top;
+    R.log_used = *bs_pool_top;
+    R.status = s_st; R.n_draws = (int64_t)s_nd; R.rounds = (int64_t)s_rounds; R.singles = (int64_t)s_singles;
+    *out = R;
 }
 
 __global__ void k_heads(const uint64_t* __restrict__ keys, int64_t E, int32_t* __restrict__ head) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= E) return;
+    if (i > E) return;
+    if (i == E) { head[E] = 0; return; }
     uint64_t k = keys[i];
     head[i] = (k != ~0ull && (i == 0 || keys[i - 1] != k)) ? 1 : 0;
 }
 
 __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const int32_t* __restrict__ head,
-                           const int32_t* __restrict__ pos, const double* __restrict__ w, int64_t E, int32_t* __restrict__ e_nbr,
-                           double* __restrict__ e_val, int32_t* __restrict__ slot_col, int32_t* __restrict__ deg) {
+                           const int32_t* __restrict__ pos, const double* __restrict__ w, int64_t E, int set_semantics,
+                           int32_t* __restrict__ e_nbr, double* __restrict__ e_val, int32_t* __restrict__ slot_col, int32_t* __restrict__ deg) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E || !head[i]) return;
     uint64_t k = keys[i];
     int32_t s = pos[i];
     double sum = w ? w[idx[i]] : 1.0;
-    for (int64_t q = i + 1; q < E && keys[q] == k; ++q) sum += w ? w[idx[q]] : 1.0;  // duplicates summed in input order
+    // duplicates summed in input order (setFromTriplets); unweighted symmetrised input is an edge SET (PyG coalesce): weight 1
+    if (!set_semantics) for (int64_t q = i + 1; q < E && keys[q] == k; ++q) sum += w ? w[idx[q]] : 1.0;
     int32_t c = (int32_t)(k >> 32);
     e_nbr[s] = (int32_t)(k & 0xFFFFFFFFull);
     e_val[s] = sum;
@@ -159,8 +261,9 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ colptr, const int32_t* __restrict__ e_nbr,
                                                   const double* __restrict__ e_val, const int32_t* __restrict__ slot_col,
-                                                  int32_t nnz, int32_t* __restrict__ e_twin, double* __restrict__ acc) {
+                                                  const int32_t* __restrict__ nnz_p, int32_t* __restrict__ e_twin, double* __restrict__ acc) {
     int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t nnz = *nnz_p;
     double d2 = 0, n2 = 0;
     if (p < nnz) {
         int32_t c = slot_col[p], r = e_nbr[p];
@@ -186,7 +289,7 @@ __global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ co
     int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sd[w] = d2; sn[w] = n2; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && (int64_t)blockIdx.x * blockDim.x < (int64_t)nnz) {
         atomicAdd(&acc[0], sd[0] + sd[1] + sd[2] + sd[3]);
         atomicAdd(&acc[1], sn[0] + sn[1] + sn[2] + sn[3]);
     }
@@ -877,8 +980,8 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     // ---- order neighbours by o_n (:295-307) ----
     {
         if (A.o_n == ON_RANDOM || coarsen) {
-            uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
-            for (int i = lane; i < m; i += 64) L.skey[i] = keyed_order_dkey(kb, L.b_nbr[i]);
+            uint64_t kb = keyed_order_base(A.shuffle_seed, v - G.vbase, 0);
+            for (int i = lane; i < m; i += 64) L.skey[i] = keyed_order_dkey(kb, L.b_nbr[i] - G.vbase);
             WAVE_SYNC();
             wave_sort_staged<false>(L, m, lane);
         } else {
@@ -1185,8 +1288,8 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
 
     // ---- order neighbours by o_n (:661-673) ----
     if (A.o_n == ON_RANDOM) {
-        const uint64_t kb = keyed_order_base(A.shuffle_seed, v, 0);
-        for (int i = lane; i < m; i += 64) { L.rec[i].key = keyed_order_dkey(kb, B.b_nbr[i]); L.rec[i].idx = i; }
+        const uint64_t kb = keyed_order_base(A.shuffle_seed, v - G.vbase, 0);
+        for (int i = lane; i < m; i += 64) { L.rec[i].key = keyed_order_dkey(kb, B.b_nbr[i] - G.vbase); L.rec[i].idx = i; }
     } else {
         for (int i = lane; i < m; i += 64) { L.rec[i].key = B.b_val[i]; L.rec[i].idx = i; }
     }
@@ -1389,7 +1492,8 @@ __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G
 // per round by every wave) small enough for the instruction cache.
 template <int OV, int ON, int BC, int NTT>
 __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
-                                                           int32_t* __restrict__ batch_pos) {
+                                                           int32_t* __restrict__ batch_pos, const int32_t* __restrict__ in_flags,
+                                                           const double* __restrict__ in_acc) {
     constexpr int NT = NTT;            // threads per workgroup
     constexpr int NWAVE = NT / 64;
     constexpr int SLOTS = PASSES * NT; // candidates x slots per round
@@ -1408,6 +1512,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     Arrays A = A_in;
     A.o_v = OV;
     A.o_n = ON;
+    A.shuffle_seed = A_in.shuffle_seed + (uint64_t)blockIdx.x;   // graph g of a batch: seed + g, ids local to the graph (rlap_core.h)
     __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end;
@@ -1417,7 +1522,15 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
-    if (tid == 0) { G = gd[g]; s_status = 0; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0; }
+    if (tid == 0) {
+        G = gd[g]; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0;
+        // the input checks of the setup kernels are read here, not on the host (no mid-call synchronisation): bad input -> nothing is eliminated
+        int32_t bad = 0;
+        if (in_flags[FLAG_RANGE]) bad = ST_INDEX_RANGE;
+        else if (in_flags[FLAG_CROSS] || in_flags[FLAG_PERM]) bad = ST_BAD_ARG;
+        else if (in_acc[2] != 0.0 || !(in_acc[0] <= 1e-24 * in_acc[1])) bad = ST_NOT_SYMMETRIC;   // isApprox(A^T), factorizers.cc:19-22
+        s_status = bad;
+    }
     for (int base = 0; base < BC - 16; base += BATCH) {   // the candidate records serve as scratch: BATCH lengths at a time
         const int row = base + tid;
         if (tid < BATCH && row < BC - 16) {
@@ -1435,7 +1548,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     const int32_t n = G.n;
     const bool use_pq = A.o_v != OV_RANDOM;
     int64_t nelim = G.t < (int64_t)(n - 1) ? G.t : (int64_t)(n - 1);
-    if (nelim < 0) nelim = 0;
+    if (nelim < 0 || s_status != 0) nelim = 0;
     int64_t done = 0;
     int32_t rounds = 0, singles = 0;
     bool pending_long = false;   // o_v = random: the last round was cut by a long column, which is therefore the next vertex
@@ -1725,7 +1838,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     Cand& C = L.cand[idx / BCAP];
                     Ent& E = C.e[rk[k]];
                     E.val = lv[k]; E.nbr = ln[k]; E.twin = lt[k];
-                    E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v, 0), ln[k]) : lv[k];
+                    E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v - G.vbase, 0), ln[k] - G.vbase) : lv[k];
                 }
             }
             if (MERGE) {
@@ -1754,7 +1867,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     if (head) {
                         Ent& E = C.e[x];
                         E.val = val; E.nbr = nb; E.twin = tw;
-                        E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v, 0), nb) : val;
+                        E.aux = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, C.v - G.vbase, 0), nb - G.vbase) : val;
                     } else if (act) {
                         C.e[m + y].twin = tw;   // dies at commit (:289)
                     }
@@ -2499,19 +2612,18 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     }
 }
 
-void launch_eliminate_batch(int o_v, int o_n, unsigned G, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
-                            int32_t* batch_pos) {
+void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
+                            int32_t* batch_pos, const int32_t* flags, const double* acc) {
     // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
     // turn comes): it runs with 64 slots per candidate (64 candidates per round); the min-degree orders with 32.
     // more graphs than CUs: the 256-thread shape, three workgroups per CU (measured on 4096-node graphs: the same
     // time per graph as the 1024-thread shape, which is only ahead when one graph offers more than 32 independent vertices a round)
-    static int n_cu = 0;
-    if (n_cu == 0) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+    if (n_cu <= 0) n_cu = 256;
     bool many = G > (unsigned)n_cu;
     if (const char* e = std::getenv("RLAP_BATCH_SHAPE")) { if (e[0] == '2') many = true; else if (e[0] == '1') many = false; }   // diagnostic override: 256 / 1024
 #define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { \
-        if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos); \
-        else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos); \
+        if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos, flags, acc); \
+        else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, flags, acc); \
         return; }
     RLAP_CASE(OV_RANDOM, ON_ASC, 64) RLAP_CASE(OV_RANDOM, ON_DESC, 64) RLAP_CASE(OV_RANDOM, ON_RANDOM, 64)
     RLAP_CASE(OV_DEGREE, ON_ASC, 32) RLAP_CASE(OV_DEGREE, ON_DESC, 32) RLAP_CASE(OV_DEGREE, ON_RANDOM, 32)
@@ -2549,7 +2661,9 @@ __global__ void k_sc_perm_order(const int64_t* __restrict__ perm, const int32_t*
     const GraphDesc& D = gd[g];
     int32_t idx = i - D.vbase;              // position in the node_id vector
     int64_t q = (int64_t)D.n - 1 - idx;     // pop number (0-based)
-    if (q >= D.n_elim) order[surv_base[g] + (q - D.n_elim)] = (uint32_t)(D.vbase + (int32_t)perm[i]);
+    int64_t pl = perm[i];
+    if (pl < 0 || pl >= (int64_t)D.n) pl = 0;   // invalid entry (flagged by k_perm_check; the call fails): keep the index in range
+    if (q >= D.n_elim) order[surv_base[g] + (q - D.n_elim)] = (uint32_t)(D.vbase + (int32_t)pl);
 }
 
 __global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __restrict__ colptr, const int32_t* __restrict__ app_cnt,
@@ -2674,14 +2788,19 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             // then the sequential form in global scratch (one lane)
             if (lane == 0 && ex > HUGECAP) {
                 unsigned long long off = atomicAdd(SS.top, (unsigned long long)ex);
+                if ((int64_t)(off + (unsigned long long)ex) > SS.cap) { SS.flags[FLAG_SCR] = 1; cnt_out[i] = 0; }   // scratch budget too small: the call is repeated with more
+                else {
                 ColBuf B = SS.colbuf((int64_t)off);
                 GraphDesc D = gd[vgraph[v]];
                 int32_t len0 = serial_gather(A, v, B, ex);
                 int32_t m = serial_sort_merge(A, D, B, len0, false, false);
-                serial_order(A, B, m, v, 1);
+                Arrays Ag = A;
+                Ag.shuffle_seed = A.shuffle_seed + (uint64_t)vgraph[v];
+                serial_order(Ag, B, m, v, 1, D.vbase);
                 for (int j = 0; j < m; ++j) { tmp_nbr[toff + j] = B.a_nbr[j]; tmp_val[toff + j] = B.a_val[j]; }
                 cnt_out[i] = m;
                 atomicAdd(live_total, (unsigned long long)len0);
+                }
             }
             __syncthreads();
             continue;
@@ -2759,12 +2878,13 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
         {
             bool done;
             if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
-                uint64_t kb = keyed_order_base(A.shuffle_seed, v, 1);
-                if (sort64(lane < m ? keyed_order_dkey(kb, L.b_nbr[lane]) : 0.0, m, false)) done = true; else
-                done = RANK_FIRST ? sc_rank_sort<false>(L, m, [&](int q) { return keyed_order_dkey(kb, L.b_nbr[q]); }, lane) : false;
+                const int32_t gi = vgraph[v], vb = gd[gi].vbase;
+                uint64_t kb = keyed_order_base(A.shuffle_seed + (uint64_t)gi, v - vb, 1);
+                if (sort64(lane < m ? keyed_order_dkey(kb, L.b_nbr[lane] - vb) : 0.0, m, false)) done = true; else
+                done = RANK_FIRST ? sc_rank_sort<false>(L, m, [&](int q) { return keyed_order_dkey(kb, L.b_nbr[q] - vb); }, lane) : false;
                 __syncthreads();
                 if (!done) {
-                    for (int q = lane; q < m; q += 64) { L.rec[q].key = keyed_order_dkey(kb, L.b_nbr[q]); L.rec[q].idx = q; }
+                    for (int q = lane; q < m; q += 64) { L.rec[q].key = keyed_order_dkey(kb, L.b_nbr[q] - vb); L.rec[q].idx = q; }
                     __syncthreads();
                     wave_std_sort<SRec, SRecLessKey, RT>(L.rec, m, SRecLessKey(), WP, lane);
                     __syncthreads();
@@ -2830,7 +2950,8 @@ __global__ __launch_bounds__(256) void k_sc_tierlists(const int32_t* __restrict_
 // in registers -- the column is read one slot per lane, compacted, ordered by id and by o_n with group_sort<32> (the
 // std::sort restatement for two 32-lane groups), merged with shuffles, and stored from the lanes.  A column whose sort
 // hits the depth limit is handed to the 64-entry kernel's list.
-__global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const uint32_t* __restrict__ order, const int64_t* __restrict__ tmp_off,
+__global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
+                                                      const uint32_t* __restrict__ order, const int64_t* __restrict__ tmp_off,
                                                       int32_t* __restrict__ tmp_nbr, double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
                                                       unsigned long long* __restrict__ live_total, const int32_t* __restrict__ worklist,
                                                       const int32_t* __restrict__ workcount, int32_t* __restrict__ list64, int32_t* __restrict__ count64) {
@@ -2924,7 +3045,11 @@ __global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const uint32_t* 
         }
         // order by o_n (:331-343) and store from the lanes
         {
-            double key = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, v, 1), nb) : val;
+            double key = val;
+            if (keyed && have) {
+                const int32_t gi = vgraph[v], vb = gd[gi].vbase;
+                key = keyed_order_dkey(keyed_order_base(A.shuffle_seed + (uint64_t)gi, v - vb, 1), nb - vb);
+            }
             int idx = gl, pos = gl;
             const bool want = have && m > 1;
             const bool okg = desc ? group_sort<true, 32>(key, idx, m, want, lane, s_tmp, &pos) : group_sort<false, 32>(key, idx, m, want, lane, s_tmp, &pos);
@@ -2947,7 +3072,7 @@ void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, c
     hipLaunchKernelGGL(k_sc_tierlists, dim3((S + 255) / 256), dim3(256), 0, stream, ext, S, keyed, lists, counts);
     unsigned gh = (unsigned)(S < 256 * 32 * 4 ? (S + 1) / 2 : 256 * 32 * 4);
     if (gh == 0) gh = 1;
-    hipLaunchKernelGGL(k_sc_merge_half, dim3(gh), dim3(64), 0, stream, A, order, tmp_off, tmp_nbr, tmp_val, cnt_out, live_total, lists + 5 * (size_t)S, counts + 5, lists, counts);
+    hipLaunchKernelGGL(k_sc_merge_half, dim3(gh), dim3(64), 0, stream, A, gd, vgraph, order, tmp_off, tmp_nbr, tmp_val, cnt_out, live_total, lists + 5 * (size_t)S, counts + 5, lists, counts);
     unsigned g0 = (unsigned)(S < 256 * 32 * 4 ? S : 256 * 32 * 4);
     unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
     unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
@@ -2966,18 +3091,20 @@ struct Rec2GreaterB { __device__ bool operator()(const Rec2& x, const Rec2& y) c
 // keyed neighbour order (o_n = random / coarsen): the key is a hash of the neighbour id, recomputed per comparison
 struct Rec2LessKeyed {
     uint64_t kb;
-    __device__ bool operator()(const Rec2& x, const Rec2& y) const { return keyed_order_dkey(kb, (int32_t)x.a) < keyed_order_dkey(kb, (int32_t)y.a); }
+    int32_t vbase;
+    __device__ bool operator()(const Rec2& x, const Rec2& y) const { return keyed_order_dkey(kb, (int32_t)x.a - vbase) < keyed_order_dkey(kb, (int32_t)y.a - vbase); }
 };
 
 // HUGE = false: SCAP < extent <= BIGCAP, records in LDS.  HUGE = true: BIGCAP < extent <= HUGECAP (a hub of a
 // weighted graph), records in global scratch (L2), both sorts by the wave-parallel restatement.
 template <bool HUGE>
-__device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+__device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
+                                                   const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
                                                    const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
                                                    const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
                                                    double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
                                                    unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists,
-                                                   Rec2* lds_R, Rec2* glob_R, unsigned long long* glob_top) {
+                                                   Rec2* lds_R, Rec2* glob_R, unsigned long long* glob_top, int64_t glob_cap, int32_t* glob_flags) {
     constexpr int LCAP = HUGE ? HUGECAP : BIGCAP;
     __shared__ uint32_t s_segmark[LCAP / 32 + 2];
     __shared__ int32_t s_stk[3 * 48];
@@ -2995,8 +3122,12 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const uint32
         const int32_t acnt = A.app_cnt[v];
         Rec2* R = lds_R;
         if (HUGE) {
-            if (lane == 0) s_off = atomicAdd(glob_top, (unsigned long long)ext[i]);
+            if (lane == 0) {
+                s_off = atomicAdd(glob_top, (unsigned long long)ext[i]);
+                if ((int64_t)(s_off + (unsigned long long)ext[i]) > glob_cap) { s_off = ~0ull; glob_flags[FLAG_SCR] = 1; cnt_out[i] = 0; }
+            }
             __syncthreads();
+            if (s_off == ~0ull) { __syncthreads(); continue; }   // scratch budget too small: the call is repeated with more
             R = glob_R + s_off;
         }
         int len0 = 0;
@@ -3054,7 +3185,7 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const uint32
             __syncthreads();
             m += popc64(mask);
         }
-        if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) { Rec2LessKeyed lk; lk.kb = keyed_order_base(A.shuffle_seed, v, 1); wave_std_sort<Rec2>(R, m, lk, WP, lane); }   // :339-343
+        if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) { const int32_t gi = vgraph[v]; Rec2LessKeyed lk; lk.vbase = gd[gi].vbase; lk.kb = keyed_order_base(A.shuffle_seed + (uint64_t)gi, v - lk.vbase, 1); wave_std_sort<Rec2>(R, m, lk, WP, lane); }   // :339-343
         else if (A.o_n == ON_ASC) wave_std_sort<Rec2>(R, m, Rec2LessB(), WP, lane);
         else wave_std_sort<Rec2>(R, m, Rec2GreaterB(), WP, lane);   // :331-338
         __syncthreads();
@@ -3064,24 +3195,27 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const uint32
     }
 }
 
-__global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+__global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
+                                                     const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
                                                      const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
                                                      const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
                                                      double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
                                                      unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists) {
     extern __shared__ Rec2 R_lds[];   // BIGCAP records
-    sc_merge_long_body<false>(A, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, R_lds, nullptr, nullptr);
+    sc_merge_long_body<false>(A, gd, vgraph, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, R_lds, nullptr, nullptr, 0, nullptr);
 }
 
-__global__ __launch_bounds__(64) void k_sc_merge_huge(Arrays A, const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+__global__ __launch_bounds__(64) void k_sc_merge_huge(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
+                                                      const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
                                                       const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
                                                       const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
                                                       double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
                                                       unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists,
-                                                      SRec* __restrict__ scratch, unsigned long long* __restrict__ scratch_top) {
+                                                      SRec* __restrict__ scratch, unsigned long long* __restrict__ scratch_top, int64_t scratch_cap,
+                                                      int32_t* __restrict__ flags) {
     static_assert(sizeof(Rec2) == sizeof(SRec), "the long-column records borrow the output pass's record scratch");
-    sc_merge_long_body<true>(A, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, nullptr,
-                             reinterpret_cast<Rec2*>(scratch), scratch_top);
+    sc_merge_long_body<true>(A, gd, vgraph, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, nullptr,
+                             reinterpret_cast<Rec2*>(scratch), scratch_top, scratch_cap, flags);
 }
 
 // Pass B (the prefix-sum compaction): row r of the output belongs to the surviving vertex i with
@@ -3093,7 +3227,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_huge(Arrays A, const uint32_t* 
 __global__ __launch_bounds__(256) void k_sc_compact(const uint32_t* __restrict__ order, const int32_t* __restrict__ cnt,
                                                     const int64_t* __restrict__ row_off, const int64_t* __restrict__ tmp_off,
                                                     const int32_t* __restrict__ tmp_nbr, const double* __restrict__ tmp_val,
-                                                    int32_t S, double* __restrict__ out) {
+                                                    int32_t S, double* __restrict__ out, int64_t out_cap) {
     (void)cnt;
     __shared__ double stage[4][192];
     const int lane = threadIdx.x & 63;
@@ -3101,6 +3235,7 @@ __global__ __launch_bounds__(256) void k_sc_compact(const uint32_t* __restrict__
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t m_total = row_off[S];
+    if (m_total > out_cap) return;   // the caller's buffer is too small: nothing is written, the row count is reported
     const int64_t ntiles = (m_total + 63) >> 6;
     const int64_t per = (ntiles + nwaves - 1) / nwaves;
     int64_t t0 = wave * per, t1 = t0 + per;

@@ -86,7 +86,8 @@ def sharded_approximate_cholesky(
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     G = len(edge_indices)
     lo, hi = shard_range(G, rank, world)
-    if compute_fn is None:
+    use_hip = compute_fn is None      # (recorded before the default is bound below: an empty shard must still hand
+    if compute_fn is None:            #  the collectives a tensor on the same kind of device as the other ranks)
         from . import ops
 
         def compute_fn(ei, w, node_ptr, nrem, o_v_, o_n_, seed_):
@@ -98,6 +99,7 @@ def sharded_approximate_cholesky(
             w = torch.cat([
                 (x.reshape(-1).to(torch.float64) if x is not None else torch.ones(e.shape[1], dtype=torch.float64))
                 for x, e in zip(edge_weights[lo:hi], edge_indices[lo:hi])])
+        # graph g of the whole list runs with seed + g whatever the sharding is (the batched call adds the local index)
         sc, row_ptr = compute_fn(ei, w, node_ptr, list(num_remove[lo:hi]), o_v, o_n, seed + lo)
         # back to per-graph local ids
         if sc.shape[0]:
@@ -108,7 +110,7 @@ def sharded_approximate_cholesky(
             sc[:, 1] -= off
         local_counts = (row_ptr[1:] - row_ptr[:-1]).cpu()
     else:
-        dev = "cuda" if (compute_fn is None and torch.cuda.is_available()) else "cpu"
+        dev = torch.device("cuda", torch.cuda.current_device()) if (use_hip and torch.cuda.is_available()) else torch.device("cpu")
         sc = torch.zeros((0, 3), dtype=torch.float64, device=dev)
         local_counts = torch.zeros(0, dtype=torch.int64)
     if not gather or world == 1:

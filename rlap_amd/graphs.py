@@ -33,7 +33,8 @@ def to_undirected(edge_index: torch.Tensor, num_nodes: int = None) -> torch.Tens
     """Device-side stand-in for the step the reference's scripts run before the op (PyG `to_undirected`,
     scripts/node_shared.py:326-327, tests/test_rlap.py:31): add the reverse of every edge and drop duplicates.
     Runs where `edge_index` lives (one sort of 64-bit keys); returns edges sorted by (row, col).  Pass `num_nodes`
-    to avoid the host sync of `edge_index.max()`."""
+    to avoid the host sync of `edge_index.max()`.  When the result only feeds the op, skip this helper:
+    `ops.approximate_cholesky_from_edges(..., symmetrize=True)` does the same inside its COO->CSR kernels."""
     if edge_index.numel() == 0:
         return edge_index
     n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1

@@ -13,6 +13,7 @@ Same positional signature, same asserts, same return contract ((m,3) float64
 """
 from typing import Optional, Sequence, Tuple, Union
 import ctypes
+import threading
 
 import torch
 from torch import Tensor
@@ -22,8 +23,29 @@ from . import _lib
 O_V = {"random": 0, "degree": 1, "coarsen": 2}
 O_N = {"asc": 0, "desc": 1, "random": 2}
 
-_handles = {}
+# One handle (workspace + stream binding) per (device, host thread): the reference builds a fresh
+# ApproximateCholesky per call (py_api_binder.cc:57), so calls from several Python threads must not share
+# state.  ctypes releases the GIL during a call, so two threads really run side by side on their streams.
+_tls = threading.local()
+_timing = False
 last_stats = None  # rlap_stats of the most recent call (dict), for benches/tests
+
+
+class _Handle:
+    def __init__(self, lib, idx):
+        self.lib = lib
+        self.ptr = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            rc = lib.rlap_create(ctypes.byref(self.ptr))
+        if rc != 0:
+            raise RuntimeError(f"rlap_create failed: {_lib.status_string(rc)}")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.rlap_destroy(self.ptr)
+        except Exception:
+            pass
 
 
 def _device_for(t: Optional[Tensor]) -> torch.device:
@@ -37,23 +59,32 @@ def _device_for(t: Optional[Tensor]) -> torch.device:
 def _handle(device: torch.device):
     lib = _lib.load()
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    h = _handles.get(idx)
-    if h is None:
-        with torch.cuda.device(idx):
-            hp = ctypes.c_void_p()
-            rc = lib.rlap_create(ctypes.byref(hp))
-            if rc != 0:
-                raise RuntimeError(f"rlap_create failed: {_lib.status_string(rc)}")
-        h = hp
-        _handles[idx] = h
+    handles = getattr(_tls, "handles", None)
+    if handles is None:
+        handles = _tls.handles = {}
+    hobj = handles.get(idx)
+    if hobj is None:
+        hobj = handles[idx] = _Handle(lib, idx)
+    h = hobj.ptr
     lib.rlap_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
+    lib.rlap_set_timing(h, 1 if _timing else 0)
     return lib, h
 
 
 def set_timing(enable: bool, device=None):
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    """Fill the ms_* fields of `last_stats` with HIP-event timings (all handles of this process)."""
+    global _timing
+    _timing = bool(enable)
+
+
+def debug_set_limits(pool_factor: float = -1.0, log_factor: float = -1.0, rng_len: int = -1, scratch_entries: int = -1, device=None):
+    """Test hook: tiny first-attempt workspace limits for the calling thread's handle, so that the
+    overflow -> retry path of the C ABI runs (last_stats["n_retries"])."""
+    dev = _device_for(None) if device is None else torch.device(device)
     lib, h = _handle(dev)
-    lib.rlap_set_timing(h, 1 if enable else 0)
+    rc = lib.rlap_debug_set_limits(h, float(pool_factor), float(log_factor), int(rng_len), int(scratch_entries))
+    if rc != 0:
+        _raise(rc)
 
 
 def _raise(rc: int):
@@ -113,11 +144,13 @@ def approximate_cholesky(
         d_perm = None
         if o_v == "random":
             if perm is None:
+                # the reference shuffles 0..n-1 with std::random_device (preconditioner.cc:594-596); here torch's
+                # device generator (or `seed`) draws it, on the device
                 gen = None
                 if seed is not None:
-                    gen = torch.Generator()
+                    gen = torch.Generator(device=dev)
                     gen.manual_seed(int(seed) & (2**63 - 1))
-                perm = torch.randperm(n, generator=gen)
+                perm = torch.randperm(n, generator=gen, device=dev)
             d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
             assert d_perm.numel() == n
         shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v == "coarsen") else 0
@@ -137,6 +170,62 @@ def approximate_cholesky(
     return res.to(return_device)
 
 
+def approximate_cholesky_from_edges(
+    edge_index: Tensor,
+    edge_weights: Optional[Tensor] = None,
+    num_nodes: Optional[int] = None,
+    num_remove: Optional[int] = None,
+    o_v: str = "random",
+    o_n: str = "asc",
+    *,
+    remove_frac: float = 0.5,
+    symmetrize: bool = True,
+    perm: Optional[Tensor] = None,
+    seed: Optional[int] = None,
+    return_device: Optional[Union[str, torch.device]] = None,
+) -> Tuple[Tensor, int]:
+    """The op with the step before it fused into its COO->CSR kernels:
+    `to_undirected` + coalesce (scripts/node_shared.py:326-327) when `symmetrize`, and
+    `num_nodes = edge_index.max() + 1`, `num_remove = int(remove_frac * num_nodes)`
+    (scripts/augmentor_benchmarks.py:77-78) when they are None -- found on the device, without a
+    torch reduction + `.item()`.  Returns (sc_edge_info on the device, num_nodes)."""
+    assert edge_index.shape[0] == 2
+    assert o_v in ["random", "degree", "coarsen"]
+    assert o_n in ["asc", "desc", "random"]
+    global last_stats
+    dev = _device_for(edge_index)
+    lib, h = _handle(dev)
+    with torch.cuda.device(dev):
+        row, col, w, E = _prep_edges(edge_index, edge_weights, dev)
+        n = -1 if num_nodes is None else int(num_nodes)
+        t = -1 if num_remove is None else int(num_remove)
+        d_perm = None
+        if o_v == "random" and perm is not None:
+            assert n >= 0, "an injected perm needs num_nodes"
+            d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+            assert d_perm.numel() == n
+        # (perm None: the node_id vector is drawn on the device from the seed)
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree") else 0
+        cap = max((2 * E) if symmetrize else E, 1)
+        out = torch.empty((cap, 3), dtype=torch.float64, device=dev)
+        rows = ctypes.c_int64(0)
+        nn = ctypes.c_int64(0)
+        st = _lib.Stats()
+        rc = lib.rlap_approx_chol_from_edges(
+            h, row.data_ptr(), col.data_ptr(), w.data_ptr() if w is not None else None, E, n, t, float(remove_frac),
+            1 if symmetrize else 0, O_V[o_v], O_N[o_n], d_perm.data_ptr() if d_perm is not None else None, shuffle_seed,
+            out.data_ptr(), out.shape[0], ctypes.byref(rows), ctypes.byref(nn), ctypes.byref(st))
+        if rc != 0:
+            _raise(rc)
+        last_stats = st.as_dict()
+        res = out[: rows.value]
+        if rows.value != out.shape[0]:
+            res = res.clone()
+    if return_device is not None and return_device != "same":
+        res = res.to(return_device)
+    return res, int(nn.value)
+
+
 def approximate_cholesky_batched(
     edge_index: Tensor,
     edge_weights: Optional[Tensor],
@@ -152,8 +241,9 @@ def approximate_cholesky_batched(
     """Batched-graph mode: graph g owns node ids [node_ptr[g], node_ptr[g+1]).
 
     Every graph is eliminated independently -- what G separate reference calls would
-    return, concatenated, with global node ids.  Returns (sc_edge_info, row_ptr[G+1]).
-    `perm` concatenates per-graph permutations of LOCAL ids.
+    return, concatenated, with global node ids: graph g's rows equal
+    `approximate_cholesky(graph g, ..., perm=perm[g], seed=seed + g)` shifted by node_ptr[g].
+    Returns (sc_edge_info, row_ptr[G+1]).  `perm` concatenates per-graph permutations of LOCAL ids.
     """
     assert edge_index.shape[0] == 2
     assert o_v in ["random", "degree", "coarsen"]
@@ -170,13 +260,11 @@ def approximate_cholesky_batched(
         N = int(np_[-1])
         d_perm = None
         if o_v == "random":
-            if perm is None:
-                gen = torch.Generator()
-                gen.manual_seed(_seed_from(seed) & (2**63 - 1))
-                perm = torch.cat([torch.randperm(int(np_[g + 1] - np_[g]), generator=gen) for g in range(G)]) if G else torch.empty(0, dtype=torch.int64)
-            d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
-            assert d_perm.numel() == N
-        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v == "coarsen") else 0
+            # perm None: every graph's node_id vector is drawn on the device from the seed (keyed shuffle, C ABI)
+            if perm is not None:
+                d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
+                assert d_perm.numel() == N
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree") else 0
         out = torch.empty((max(E, 1), 3), dtype=torch.float64, device=dev)
         row_ptr = torch.zeros(G + 1, dtype=torch.int64)
         st = _lib.Stats()
@@ -189,6 +277,8 @@ def approximate_cholesky_batched(
             _raise(rc)
         last_stats = st.as_dict()
         res = out[: int(row_ptr[-1])]
+        if res.shape[0] != out.shape[0]:
+            res = res.clone()   # do not pin the (E,3) buffer behind a shorter view
     if return_device is not None and return_device != "same":
         res = res.to(return_device)
     return res, row_ptr

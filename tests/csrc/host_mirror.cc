@@ -346,6 +346,11 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
 
 extern "C" {
 
+// the keyed neighbour order as the kernels compile it (rlap_core.h), for tests/test_keyed_order.py
+double mirror_keyed_key(uint64_t seed, int64_t vertex, int phase, int64_t nbr) {
+    return keyed_order_dkey(keyed_order_base(seed, vertex, phase), nbr);
+}
+
 // std_sort_emul permutation of doubles: perm_out[i] = original index ending at i.
 void mirror_sort_perm(const double* keys, int64_t n, int desc, int64_t* perm_out) {
     std::vector<SRec> r((size_t)n);

@@ -362,22 +362,21 @@ def test_batched_equals_separate_calls(ops):
         ei = ba_graph(n, m, 40 + g) if n > m else np.zeros((2, 0), dtype=np.int64)
         eis.append(torch.from_numpy(ei)); ns.append(n); ts.append(n // 2)
     big, node_ptr = graphs.batch_disjoint(eis, ns)
-    for o_v, o_n in [("degree", "asc"), ("random", "desc"), ("coarsen", "asc")]:
+    for o_v, o_n in [("degree", "asc"), ("random", "desc"), ("coarsen", "asc"), ("degree", "random"), ("random", "random")]:
         perms = [np.random.RandomState(g).permutation(n) for g, n in enumerate(ns)]
         perm = torch.from_numpy(np.concatenate(perms)) if o_v == "random" else None
         sc, row_ptr = ops.approximate_cholesky_batched(big.cuda(), None, node_ptr, ts, o_v, o_n, perm=perm, seed=5)
         sc = sc.cpu().numpy()
         for g in range(12):
-            # keyed neighbour order hashes GLOBAL vertex ids: shift the oracle's graph to the same ids
+            # the batched contract (include/rlap_hip.h): graph g == a separate call on graph g with seed + g
             off = int(node_ptr[g])
-            ei_g = eis[g].numpy() + off
-            n_glob = off + ns[g]
-            if o_v == "coarsen":
-                continue  # pop order of a shifted single graph includes the isolated prefix; covered below
-            a = oracle.approximate_cholesky(eis[g].numpy(), None, ns[g], ts[g], o_v, o_n, perm=perms[g], shuffle_seed=5)
+            a = oracle.approximate_cholesky(eis[g].numpy(), None, ns[g], ts[g], o_v, o_n, perm=perms[g], shuffle_seed=5 + g)
             b = sc[int(row_ptr[g]):int(row_ptr[g + 1])].copy()
             b[:, :2] -= off
             assert_same(b, a, f"graph {g} {o_v}/{o_n}")
+            if g in (3, 7):   # ... and == a separate call of the op itself
+                c = gpu_call(ops, eis[g].numpy(), None, ns[g], ts[g], o_v, o_n, perm=perms[g], seed=5 + g)
+                assert_same(b, c, f"graph {g} {o_v}/{o_n} vs single call")
         # whole-batch invariants for every mode: symmetric edge set inside each graph's id range
         for g in range(12):
             b = sc[int(row_ptr[g]):int(row_ptr[g + 1])]
@@ -387,7 +386,7 @@ def test_batched_equals_separate_calls(ops):
                 assert all((c, r) in fw for r, c in fw)
 
 
-@pytest.mark.parametrize("o_v,o_n", [("degree", "asc"), ("degree", "random"), ("random", "asc"), ("random", "desc")])
+@pytest.mark.parametrize("o_v,o_n", [("degree", "asc"), ("degree", "random"), ("random", "asc"), ("random", "desc"), ("coarsen", "asc"), ("random", "random")])
 def test_batched_many_graphs(ops, o_v, o_n):
     """More graphs than twice the CUs: the batch runs with the 256-thread workgroup shape (three per CU).
     Every 16th graph is compared with the oracle; sizes include dense ones whose columns leave the 32/64-slot
@@ -412,12 +411,7 @@ def test_batched_many_graphs(ops, o_v, o_n):
     sc = sc.cpu().numpy()
     for g in list(range(0, G, 16)) + list(range(1, G, 16)) + list(range(2, G, 37)):
         off = int(node_ptr[g])
-        if o_n == "random":   # keyed neighbour order hashes GLOBAL vertex ids: only the structure is compared
-            b = sc[int(row_ptr[g]):int(row_ptr[g + 1])]
-            fw = set(map(tuple, b[:, :2].astype(int)))
-            assert all((c, r) in fw for r, c in fw)
-            continue
-        a = oracle.approximate_cholesky(eis[g].numpy(), None, ns[g], ts[g], o_v, o_n, perm=perms[g], shuffle_seed=5)
+        a = oracle.approximate_cholesky(eis[g].numpy(), None, ns[g], ts[g], o_v, o_n, perm=perms[g], shuffle_seed=5 + g)
         b = sc[int(row_ptr[g]):int(row_ptr[g + 1])].copy()
         b[:, :2] -= off
         assert_same(b, a, f"graph {g} {o_v}/{o_n}")
@@ -483,6 +477,8 @@ def test_ppr_diffusion_adapter(ops):
     d = A.sum(1); dinv = np.where(d > 0, d ** -0.5, 0)
     S = 0.2 * np.linalg.inv(np.eye(len(nodes)) - 0.8 * (dinv[:, None] * A * dinv[None, :]))
     S[S < 1e-4] = 0
+    d2 = S.sum(1); d2inv = np.where(d2 > 0, d2 ** -0.5, 0)
+    S = d2inv[:, None] * S * d2inv[None, :]       # the closing transition_matrix('sym') of PyGCL's compute_ppr (unpinned: PyGCL absent)
     got = np.zeros_like(S)
     gi = g.edge_index.cpu().numpy(); got[rel[gi[0]], rel[gi[1]]] = g.edge_weights.cpu().numpy()
     assert np.allclose(got, S, rtol=1e-8, atol=1e-12)
@@ -512,3 +508,187 @@ def test_large_graph_properties(ops):
         # run twice: same result (deterministic for degree; coarsen with a fixed seed)
         sc2 = ops.approximate_cholesky(ei, None, n, n // 2, o_v, "asc", seed=3, return_device="same")
         assert torch.equal(sc, sc2)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 5 at full size: 1024 x BA(4096, m=8), num_remove = 2048 each, one batched call per mode;
+# EVERY graph is compared with the oracle for the two headline modes (about 20 s of CPU).
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config5():
+    from rlap_amd import graphs
+    G, n, m = 1024, 4096, 8
+    eis = [graphs.barabasi_albert(n, m, 1000 + g) for g in range(G)]
+    big, node_ptr = graphs.batch_disjoint(eis, [n] * G)
+    perms = [np.random.RandomState(g).permutation(n) for g in range(G)]
+    return G, n, eis, big.cuda(), node_ptr, perms
+
+
+@pytest.mark.parametrize("o_v,o_n,every", [("degree", "asc", 1), ("random", "asc", 1), ("coarsen", "asc", 16), ("degree", "random", 16), ("random", "random", 16)])
+def test_config5_full_size(ops, config5, o_v, o_n, every):
+    G, n, eis, big, node_ptr, perms = config5
+    perm = torch.from_numpy(np.concatenate(perms)) if o_v == "random" else None
+    sc, rp = ops.approximate_cholesky_batched(big, None, node_ptr, [n // 2] * G, o_v, o_n, perm=perm, seed=5)
+    assert ops.last_stats["n_eliminated"] == G * (n // 2)
+    sc = sc.cpu().numpy()
+    for g in range(0, G, every):
+        ref = oracle.approximate_cholesky(eis[g].numpy(), None, n, n // 2, o_v, o_n, perm=perms[g], shuffle_seed=5 + g)
+        got = sc[int(rp[g]):int(rp[g + 1])].copy()
+        got[:, :2] -= g * n
+        assert_same(got, ref, f"config 5 graph {g} {o_v}/{o_n}")
+
+
+def test_bad_perm_is_rejected(ops):
+    # the injected node_id vector is validated on the device (range + duplicates) -> ValueError, no fault
+    n = 300
+    ei = torch.from_numpy(ba_graph(n, 3, 1)).cuda()
+    good = np.random.RandomState(0).permutation(n)
+    for bad in (np.where(good == 5, n + 7, good), np.where(good == 5, -1, good), np.where(good == 5, 6, good)):
+        with pytest.raises(ValueError):
+            ops.approximate_cholesky(ei, None, n, n // 2, "random", "asc", perm=torch.from_numpy(bad))
+    # batched: GLOBAL ids where LOCAL ids are expected (the likeliest mistake)
+    from rlap_amd import graphs
+    eis = [torch.from_numpy(ba_graph(50, 3, g)) for g in range(3)]
+    big, node_ptr = graphs.batch_disjoint(eis, [50] * 3)
+    glob = torch.cat([torch.from_numpy(np.random.RandomState(g).permutation(50)) + 50 * g for g in range(3)])
+    with pytest.raises(ValueError):
+        ops.approximate_cholesky_batched(big.cuda(), None, node_ptr, [25] * 3, "random", "asc", perm=glob)
+    # and the handle still works afterwards
+    a = oracle.approximate_cholesky(ei.cpu().numpy(), None, n, n // 2, "random", "asc", perm=good)
+    b = gpu_call(ops, ei.cpu().numpy(), None, n, n // 2, "random", "asc", perm=good)
+    assert_same(b, a, "after rejected perms")
+
+
+@pytest.mark.parametrize("kind", ["pool", "log", "rng", "scratch"])
+def test_overflow_retry_path(ops, kind):
+    """The growth limits of the workspace (append pool, PQ log, uniform table, long-column scratch) are hit on
+    purpose (rlap_debug_set_limits): the call must repeat itself and still return the oracle's rows."""
+    if kind == "scratch":
+        n = 12000; ei = star(n); w = sym_weights(ei, n, 2); o_v, o_n, t = "degree", "asc", 0     # a surviving column beyond 8192 entries
+    else:
+        n = 3000; ei = ba_graph(n, 6, 9); w = None; o_v, o_n, t = "degree", "asc", n // 2
+    ref = oracle.approximate_cholesky(ei, w, n, t, o_v, o_n)
+    lim = {"pool": dict(pool_factor=0.0), "log": dict(log_factor=0.0), "rng": dict(rng_len=100), "scratch": dict(scratch_entries=64)}[kind]
+    ops.debug_set_limits(**lim)
+    try:
+        got = gpu_call(ops, ei, w, n, t, o_v, o_n)
+        retries = ops.last_stats["n_retries"]
+    finally:
+        ops.debug_set_limits()
+    assert_same(got, ref, f"retry {kind}")
+    assert retries > 0, f"{kind}: the limit was not hit"
+    got = gpu_call(ops, ei, w, n, t, o_v, o_n)
+    assert ops.last_stats["n_retries"] == 0
+    assert_same(got, ref, f"after retry {kind}")
+
+
+def test_two_threads_two_streams(ops):
+    """Re-entrancy (reference: a fresh ApproximateCholesky per call, py_api_binder.cc:57): two Python threads, each on
+    its own stream, call the op concurrently; every result is bit-exact."""
+    import threading
+    jobs = []
+    for k in range(2):
+        n = 6000 + 500 * k
+        ei = ba_graph(n, 5 + k, 30 + k)
+        perm = np.random.RandomState(k).permutation(n)
+        jobs.append((n, ei, perm, oracle.approximate_cholesky(ei, None, n, n // 2, "degree", "asc"),
+                     oracle.approximate_cholesky(ei, None, n, n // 2, "random", "asc", perm=perm)))
+    errors = []
+
+    def worker(k):
+        try:
+            n, ei, perm, ref_d, ref_r = jobs[k]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ei_t = torch.from_numpy(ei).cuda()
+                for _ in range(6):
+                    a = ops.approximate_cholesky(ei_t, None, n, n // 2, "degree", "asc").numpy()
+                    b = ops.approximate_cholesky(ei_t, None, n, n // 2, "random", "asc", perm=torch.from_numpy(perm)).numpy()
+                    assert a.shape == ref_d.shape and np.array_equal(a, ref_d)
+                    assert b.shape == ref_r.shape and np.array_equal(b, ref_r)
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+
+
+def test_from_edges_fused_symmetrise_and_num_nodes(ops):
+    # SURVEY 8(f) rank 2: one-directional edges in, to_undirected + coalesce + num_nodes = max + 1 inside the op
+    rs = np.random.RandomState(3)
+    n = 700
+    src = rs.randint(0, n - 40, 4000); dst = rs.randint(0, n - 40, 4000)      # ids stop short of n: max + 1 < n
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    from util import symmetrize
+    und = symmetrize(src.astype(np.int64), dst.astype(np.int64), n)
+    n_ref = int(und.max()) + 1
+    for o_v, o_n in (("degree", "asc"), ("coarsen", "asc"), ("degree", "random")):
+        ref = oracle.approximate_cholesky(und, None, n_ref, int(0.5 * n_ref), o_v, o_n, shuffle_seed=11)
+        got, nn = ops.approximate_cholesky_from_edges(torch.from_numpy(np.stack([src, dst])).cuda(), None, None, None, o_v, o_n,
+                                                      remove_frac=0.5, symmetrize=True, seed=11)
+        assert nn == n_ref and got.is_cuda
+        assert_same(got.cpu().numpy(), ref, f"from_edges {o_v}/{o_n}")
+    # weighted, both directions present once: PyG to_undirected(reduce="add") semantics = summed duplicates
+    w1 = rs.uniform(0.5, 1.5, src.shape[0])
+    both_r = np.concatenate([src, dst]); both_c = np.concatenate([dst, src]); both_w = np.concatenate([w1, w1])
+    ref = oracle.approximate_cholesky(np.stack([both_r, both_c]), both_w, n_ref, 100, "degree", "asc")
+    got, _ = ops.approximate_cholesky_from_edges(torch.from_numpy(np.stack([src, dst])).cuda(), torch.from_numpy(w1).cuda(), None, 100,
+                                                 "degree", "asc", symmetrize=True)
+    a, b = canonical(got.cpu().numpy()), canonical(ref)
+    assert a.shape == b.shape and np.array_equal(a[:, :2], b[:, :2]) and np.allclose(a[:, 2], b[:, 2], rtol=1e-12)
+    # o_v="random" without an injected perm: the node_id vector is drawn on the device -> valid, symmetric, reproducible
+    ei = torch.from_numpy(ba_graph(500, 4, 3)).cuda()
+    r1, _ = ops.approximate_cholesky_from_edges(ei, None, 500, 250, "random", "asc", symmetrize=False, seed=99)
+    r2, _ = ops.approximate_cholesky_from_edges(ei, None, 500, 250, "random", "asc", symmetrize=False, seed=99)
+    r3, _ = ops.approximate_cholesky_from_edges(ei, None, 500, 250, "random", "asc", symmetrize=False, seed=100)
+    assert torch.equal(r1, r2) and not (r1.shape == r3.shape and torch.equal(r1, r3))
+    fw = set(map(tuple, r1[:, :2].long().cpu().numpy()))
+    assert all((c, r) in fw for r, c in fw)
+    assert torch.unique(r1[:, 1]).numel() <= 250
+
+
+def test_adapter_num_nodes_rule(ops):
+    # reference rule (augmentor_benchmarks.py:77): num_nodes = edge_index.max() + 1, even when x has more rows
+    from rlap_amd.adapters import rLap
+    n = 400
+    ei = ba_graph(n, 5, 12)
+    x = torch.randn(n + 30, 8, device="cuda")            # 30 trailing isolated nodes
+    g = rLap(0.5, o_v="degree", o_n="asc")(x, torch.from_numpy(ei).cuda(), None)
+    ref = oracle.approximate_cholesky(ei, None, n, n // 2, "degree", "asc")
+    assert np.array_equal(g.edge_index.cpu().numpy(), ref[:, :2].astype(np.int64).T)
+    g2 = rLap(0.5, o_v="degree", o_n="asc", num_nodes_from_x=True)(x, torch.from_numpy(ei).cuda(), None)
+    ref2 = oracle.approximate_cholesky(ei, None, n + 30, (n + 30) // 2, "degree", "asc")
+    assert np.array_equal(g2.edge_index.cpu().numpy(), ref2[:, :2].astype(np.int64).T)
+
+
+def _load_edge_list(path):
+    """(2,E) int64 from .npy / .npz (first array) / whitespace text with two columns."""
+    if path.endswith(".npy"):
+        a = np.load(path)
+    elif path.endswith(".npz"):
+        z = np.load(path); a = z[z.files[0]]
+    else:
+        a = np.loadtxt(path, dtype=np.int64)
+    a = np.asarray(a, dtype=np.int64)
+    return a if a.shape[0] == 2 else a.T
+
+
+@pytest.mark.parametrize("env,o_v", [("RLAP_CORA_EDGES", "random"), ("RLAP_ARXIV_EDGES", "coarsen")])
+def test_real_datasets_if_present(ops, env, o_v):
+    """BASELINE configs 2 (Cora) and 4 (ogbn-arxiv): the datasets are not in the image; point the environment variable
+    at an edge list (.npy/.npz/.txt, either orientation) to run them.  The BA stand-ins above cover the same modes."""
+    path = os.environ.get(env)
+    if not path or not os.path.exists(path):
+        pytest.skip(f"{env} not set: dataset absent from this image")
+    from util import symmetrize
+    raw = _load_edge_list(path)
+    keep = raw[0] != raw[1]
+    n = int(raw.max()) + 1
+    und = symmetrize(raw[0][keep], raw[1][keep], n)      # scripts/node_shared.py:326-327 (to_undirected)
+    perm = np.random.RandomState(0).permutation(n) if o_v == "random" else None
+    ref = oracle.approximate_cholesky(und, None, n, n // 2, o_v, "asc", perm=perm, shuffle_seed=3)
+    got = gpu_call(ops, und, None, n, n // 2, o_v, "asc", perm=perm, seed=3)
+    assert_same(got, ref, f"{env} {o_v}/asc")

@@ -1,7 +1,9 @@
 """BASELINE config 5: batch of 1024 BA(4096, m=8) graphs, num_remove = N/2 each, one launch.
 Checks a sample of graphs against the oracle and reports throughput."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from rlap_amd import graphs, ops
 import oracle

@@ -1,6 +1,8 @@
 """Seeded sweep of the batched mode (both workgroup shapes): many random graphs per call, every graph compared with the oracle."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from rlap_amd import graphs, ops
 import oracle
@@ -32,7 +34,7 @@ for call in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
             fw = set(map(tuple, b[:, :2].astype(int)))
             ok = all((c, r) in fw for r, c in fw)
         else:
-            ref = oracle.approximate_cholesky(eis[g].numpy(), None, ns[g], ts[g], o_v, o_n, perm=perms[g], shuffle_seed=5)
+            ref = oracle.approximate_cholesky(eis[g].numpy(), None, ns[g], ts[g], o_v, o_n, perm=perms[g], shuffle_seed=5 + g)
             got = sc[int(rp[g]):int(rp[g + 1])].copy(); got[:, :2] -= int(node_ptr[g])
             ok = got.shape == ref.shape and np.array_equal(got, ref)
         total += 1

@@ -1,7 +1,9 @@
 """Seeded sweep over medium graphs (BA with various m, grids, random regular-ish) x all modes x weights against the oracle.
 Run on the GPU box; prints a line per failure and a summary."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from rlap_amd import ops
 import oracle

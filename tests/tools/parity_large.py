@@ -1,6 +1,8 @@
 """Oracle parity at BASELINE-config sizes for the non-headline modes (run on the GPU box)."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from rlap_amd import graphs, ops
 import oracle

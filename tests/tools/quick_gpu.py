@@ -1,5 +1,7 @@
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 import oracle
 from util import *

@@ -1,6 +1,8 @@
 """Latency of one small call (BASELINE config 2 stand-in: BA(2708, m=2), t=N/2, o_v=random) against the CPU port."""
 import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, _ROOT); sys.path.insert(0, os.path.join(_ROOT, 'tests'))
 import numpy as np, torch
 from rlap_amd import graphs, ops
 import oracle

@@ -1,5 +1,5 @@
 import sys, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlap_amd import graphs, ops
 G,n,m=64,4096,8
 eis=[graphs.barabasi_albert(n,m,1000+g) for g in range(G)]

@@ -1,5 +1,5 @@
 import sys, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlap_amd import graphs, ops
 n=1_000_000
 ei=graphs.barabasi_albert(n,10,2).cuda()

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlap_amd import ops
 lib, h = ops._handle(torch.device("cuda", 0))
 rng = np.random.RandomState(0)
