@@ -52,6 +52,8 @@ struct rlap_handle_s {
     hipStream_t stream = nullptr;
     bool timing = false;
     hipEvent_t ev[8];
+    hipStream_t side[2] = {nullptr, nullptr};   // the output pass's independent tiers run side by side
+    hipEvent_t fork_ev[3];
     // setup
     DevBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, permchk, genperm;
     // graph state
@@ -82,8 +84,9 @@ struct Scalars {
     int32_t flags[FLAG_COUNT];
     int32_t nnz; int32_t pad;
     double acc[4];
-    unsigned long long counters[8];   // [0] sc scratch top, [1] live total, [4..6] tier counts (6 ints)
+    unsigned long long counters[8];   // [0] sc scratch top, [4..6] tier counts (6 ints)
     unsigned long long maxid;
+    unsigned long long live[LIVE_SLOTS * LIVE_STRIDE];   // live entries read by the output pass, partial sums
 };
 
 int ensure_rng(rlap_handle h, int64_t count) {
@@ -217,7 +220,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     ENSURE(h->head, 4 * (Ealloc + 1)); ENSURE(h->pos, 4 * (Ealloc + 1));
     ENSURE(h->e_nbr, 4 * slot_cap); ENSURE(h->e_val, 8 * slot_cap); ENSURE(h->e_twin, 4 * slot_cap);
     ENSURE(h->slot_col, 4 * Ealloc);
-    ENSURE(h->deg, 4 * (N + 1)); ENSURE(h->colptr, 4 * (N + 1));
+    ENSURE(h->colptr, 4 * (N + 1));
     ENSURE(h->gd_d, sizeof(GraphDesc) * G);
     ENSURE(h->app_cnt, 4 * N); ENSURE(h->app_chunk, 4 * N); ENSURE(h->key, 4 * N); ENSURE(h->pqpos, 4 * N);
     ENSURE(h->origpos, 4 * N);
@@ -235,7 +238,6 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     ENSURE(h->sc_rec, sizeof(SRec) * scr_budget); ENSURE(h->sc_i32, 4 * 7 * scr_budget); ENSURE(h->sc_f64, 8 * 2 * scr_budget);
     ENSURE(h->biglist, 4 * 6 * (S + 1));
     ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
-    constexpr unsigned NHUGE = 32;
     ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
     ENSURE(h->out_ptr_d, 8 * (G + 1));
     const size_t res_bytes = sizeof(CallResults) + 8 * (size_t)(G + 1);
@@ -258,7 +260,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     Scalars* SC = h->scal.as<Scalars>();
     int32_t* flags = SC->flags;
     double* acc = SC->acc;
-    unsigned long long* counters = SC->counters;   // [0] sc scratch top, [1] live total
+    unsigned long long* counters = SC->counters;   // [0] sc scratch top
+    unsigned long long* live = SC->live;
     int32_t* nnz_p = &SC->nnz;
 
     // ---------------- setup: COO -> CSR ----------------
@@ -268,7 +271,6 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     {
         Fills F;
         F.add(h->scal.p, sizeof(Scalars) / 4, 0);
-        F.add(h->deg.p, N + 1, 0);
         F.add(h->bs_cnt.p, bucket_total, 0); F.add(h->bs_alloc.p, bucket_total, 0);
         F.add(h->ocur.p, bucket_total, 0); F.add(h->oend.p, bucket_total, 0);
         F.add(h->bs_pool_top.p, 1, 0);
@@ -291,11 +293,11 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         HIPCHK(hipMemcpyAsync(nnz_p, h->pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), h->idx1.as<uint32_t>(), h->head.as<int32_t>(),
                            h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
-                           h->slot_col.as<int32_t>(), h->deg.as<int32_t>());
+                           h->slot_col.as<int32_t>());
     }
-    { int rc = excl_scan(h, h->deg.as<int32_t>(), h->colptr.as<int32_t>(), N + 1); if (rc) return rc; }
+    hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, h->slot_col.as<int32_t>(), nnz_p, (int32_t)N, h->colptr.as<int32_t>());
     if (Eeff > 0)
-        hipLaunchKernelGGL(k_twin_sym, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
+        hipLaunchKernelGGL(k_twin_sym, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
                            h->slot_col.as<int32_t>(), nnz_p, h->e_twin.as<int32_t>(), acc);
     HIPCHK(hipMemcpyAsync(h->pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
     // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)
@@ -384,24 +386,16 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
     if (S > 0) {
         int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 6 ints: tiers 0..5
-        launch_sc_merge(s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
-                        h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, counters + 1, h->biglist.as<int32_t>(), tiercounts);
-        HIPCHK(hipGetLastError());
-        // long columns: whole column in LDS, one single-wave workgroup each
-        int32_t* bigcount = tiercounts + 3;
-        int32_t* biglist_ptr = h->biglist.as<int32_t>() + 3 * (size_t)S;
         if (!h->big_attr_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIGCAP * 16));
             h->big_attr_set = true;
         }
-        hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
-                           biglist_ptr, bigcount, h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1,
-                           h->biglists.as<uint16_t>());
-        HIPCHK(hipGetLastError());
-        // longer than the LDS record array (hubs of weighted graphs): records in global scratch, a few workgroups
-        hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(),
-                           h->biglist.as<int32_t>() + 4 * (size_t)S, tiercounts + 4, h->tmp_nbr.as<int32_t>(),
-                           h->tmp_val.as<double>(), h->cnt.as<int32_t>(), counters + 1, h->hugelists.as<uint16_t>(), SS.rec, SS.top, SS.cap, flags);
+        ScLaunch X;
+        X.main = s; X.side[0] = h->side[0]; X.side[1] = h->side[1];
+        for (int q = 0; q < 3; ++q) X.ev[q] = h->fork_ev[q];
+        launch_sc_merge(X, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
+                        h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, live, h->biglist.as<int32_t>(), tiercounts,
+                        h->biglists.as<uint16_t>(), h->hugelists.as<uint16_t>());
         HIPCHK(hipGetLastError());
     }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[4], s));
@@ -419,7 +413,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     CallResults* res_d = h->results.as<CallResults>();
     int64_t* out_ptr_d = reinterpret_cast<int64_t*>(res_d + 1);
     hipLaunchKernelGGL(k_graph_rows, dim3(nblk(G + 1, 256)), dim3(256), 0, s, h->surv_base_d.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)G, out_ptr_d);
-    hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, s, flags, acc, nnz_p, counters, h->tmp_off.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)S,
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, s, flags, acc, nnz_p, counters, live, h->tmp_off.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)S,
                        h->gd_d.as<GraphDesc>(), (int32_t)G, h->pool_top.as<int32_t>(), h->bs_pool_top.as<int32_t>(), res_d);
     HIPCHK(hipMemcpyAsync(h->h_results, h->results.p, res_bytes, hipMemcpyDeviceToHost, s));
     if (h->timing) HIPCHK(hipEventRecord(h->ev[7], s));
@@ -507,6 +501,8 @@ int rlap_create(rlap_handle* out) {
     h->device = dev;
     if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
     for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
+    for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& st : h->side) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     *out = h;
     return RLAP_OK;
 }
@@ -522,6 +518,8 @@ int rlap_destroy(rlap_handle h) {
     if (h->h_results) (void)hipHostFree(h->h_results);
     for (DevBuf* b : bufs) b->release();
     for (auto& e : h->ev) (void)hipEventDestroy(e);
+    for (auto& e : h->fork_ev) (void)hipEventDestroy(e);
+    for (auto& st : h->side) if (st) (void)hipStreamDestroy(st);
     delete h;
     return RLAP_OK;
 }

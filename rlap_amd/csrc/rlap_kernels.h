@@ -26,6 +26,8 @@ constexpr int SCAP = 512;  // output pass: same
 constexpr int BIGCAP = 8192;  // output pass, long columns: one workgroup with a 128 KB LDS record array
 constexpr int POOL_GRAB_BIG = 16384;   // append slots a 1024-thread workgroup reserves at a time (256-thread: POOL_GRAB_SMALL)
 constexpr int POOL_GRAB_SMALL = 2048;
+constexpr int LIVE_SLOTS = 64;   // the output pass sums its live-entry count into this many counters, LIVE_STRIDE words apart
+constexpr int LIVE_STRIDE = 16;
 constexpr int HUGECAP = 65535; // output pass, longer still: records in global scratch (uint16 stop lists)
 
 // Global scratch for columns too long for LDS (sequential fallback).
@@ -76,11 +78,12 @@ __global__ void k_fill_multi(FillJobs J);
 __global__ void k_perm_check(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, int32_t N, int32_t* seen, int32_t* flags);
 __global__ void k_gd_scratch(const int32_t* colptr, const int64_t* node_ptr, int32_t G, GraphDesc* gd);
 __global__ void k_collect(const int32_t* flags, const double* acc, const int32_t* nnz_p, const unsigned long long* counters,
-                          const int64_t* tmp_off, const int64_t* row_off, int32_t S, const GraphDesc* gd, int32_t G,
+                          const unsigned long long* live, const int64_t* tmp_off, const int64_t* row_off, int32_t S, const GraphDesc* gd, int32_t G,
                           const int32_t* pool_top, const int32_t* bs_pool_top, CallResults* out);
 __global__ void k_heads(const uint64_t* keys, int64_t E, int32_t* head);
 __global__ void k_fill_csr(const uint64_t* keys, const uint32_t* idx, const int32_t* head, const int32_t* pos, const double* w,
-                           int64_t E, int set_semantics, int32_t* e_nbr, double* e_val, int32_t* slot_col, int32_t* deg);
+                           int64_t E, int set_semantics, int32_t* e_nbr, double* e_val, int32_t* slot_col);
+__global__ void k_colptr(const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int32_t* colptr);
 __global__ void k_twin_sym(const int32_t* colptr, const int32_t* e_nbr, const double* e_val, const int32_t* slot_col, const int32_t* nnz_p,
                            int32_t* e_twin, double* acc);
 __global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, int32_t* key, int32_t* pqpos, int32_t* app_cnt,
@@ -94,9 +97,11 @@ __global__ void k_sc_keys(const int32_t* key, const int32_t* pqpos, const int32_
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,
                                 uint32_t* order);
 __global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const int32_t* app_cnt, int32_t S, int32_t* ext);
-void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
+constexpr unsigned NHUGE = 32;   // workgroups of k_sc_merge_huge
+struct ScLaunch { hipStream_t main; hipStream_t side[2]; hipEvent_t ev[3]; };   // side streams may be null: everything on `main`
+void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
-                     unsigned long long* live_total, int32_t* lists, int32_t* counts);
+                     unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* biglists, uint16_t* hugelists);
 __global__ void k_debug_wave_sort(const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out);
 __global__ void k_sc_merge_big(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
                                int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists);

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256) void k_gd_scratch(const int32_t* __restrict__ 
 
 // everything the host wants to know about a call, gathered into one block (one D2H copy at the end)
 __global__ __launch_bounds__(256) void k_collect(const int32_t* __restrict__ flags, const double* __restrict__ acc, const int32_t* __restrict__ nnz_p,
-                          const unsigned long long* __restrict__ counters, const int64_t* __restrict__ tmp_off, const int64_t* __restrict__ row_off,
+                          const unsigned long long* __restrict__ counters, const unsigned long long* __restrict__ live,
+                          const int64_t* __restrict__ tmp_off, const int64_t* __restrict__ row_off,
                           int32_t S, const GraphDesc* __restrict__ gd, int32_t G, const int32_t* __restrict__ pool_top,
                           const int32_t* __restrict__ bs_pool_top, CallResults* __restrict__ out) {
     __shared__ int32_t s_st;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void k_collect(const int32_t* __restrict__ fla
     for (int q = 0; q < FLAG_COUNT; ++q) R.flags[q] = flags[q];
     for (int q = 0; q < 4; ++q) R.acc[q] = acc[q];
     R.nnz = *nnz_p;
-    R.live_total = (int64_t)counters[1];
+    { unsigned long long lt = 0ull; for (int q = 0; q < LIVE_SLOTS; ++q) lt += live[q * LIVE_STRIDE]; R.live_total = (int64_t)lt; }
     R.scr_need = (int64_t)counters[0];
     R.ext_total = tmp_off[S];
     R.m_total = row_off[S];
@@ -240,7 +241,7 @@ __global__ void k_heads(const uint64_t* __restrict__ keys, int64_t E, int32_t* _
 
 __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const int32_t* __restrict__ head,
                            const int32_t* __restrict__ pos, const double* __restrict__ w, int64_t E, int set_semantics,
-                           int32_t* __restrict__ e_nbr, double* __restrict__ e_val, int32_t* __restrict__ slot_col, int32_t* __restrict__ deg) {
+                           int32_t* __restrict__ e_nbr, double* __restrict__ e_val, int32_t* __restrict__ slot_col) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E || !head[i]) return;
     uint64_t k = keys[i];
@@ -252,7 +253,18 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
     e_nbr[s] = (int32_t)(k & 0xFFFFFFFFull);
     e_val[s] = sum;
     slot_col[s] = c;
-    atomicAdd(&deg[c], 1);
+}
+
+// colptr[c] = first slot whose column is >= c (slots are sorted by column): no atomics, empty columns included
+__global__ void k_colptr(const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nnz_p, int32_t N, int32_t* __restrict__ colptr) {
+    int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > N) return;
+    int32_t lo = 0, hi = *nnz_p;
+    while (lo < hi) {
+        int32_t mid = (lo + hi) >> 1;
+        if (slot_col[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    colptr[c] = lo;
 }
 
 // ---------------------------------------------------------------------------
@@ -262,36 +274,39 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
 __global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ colptr, const int32_t* __restrict__ e_nbr,
                                                   const double* __restrict__ e_val, const int32_t* __restrict__ slot_col,
                                                   const int32_t* __restrict__ nnz_p, int32_t* __restrict__ e_twin, double* __restrict__ acc) {
-    int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t nnz = *nnz_p;
     double d2 = 0, n2 = 0;
-    if (p < nnz) {
+    bool asym = false;
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += gridDim.x * blockDim.x) {
         int32_t c = slot_col[p], r = e_nbr[p];
         double v = e_val[p];
-        n2 = v * v;
+        n2 += v * v;
         int32_t lo = colptr[r], hi = colptr[r + 1];
+        const int32_t end = hi;
         while (lo < hi) {
             int32_t mid = (lo + hi) >> 1;
             if (e_nbr[mid] < c) lo = mid + 1; else hi = mid;
         }
-        if (lo < colptr[r + 1] && e_nbr[lo] == c) {
+        if (lo < end && e_nbr[lo] == c) {
             e_twin[p] = lo;
             double d = v - e_val[lo];
-            d2 = d * d;
+            d2 += d * d;
         } else {
             e_twin[p] = -1;
-            d2 = 2 * v * v;
-            acc[2] = 1.0;  // structurally asymmetric
+            d2 += 2 * v * v;
+            asym = true;
         }
     }
+    if (asym) acc[2] = 1.0;  // structurally asymmetric
     for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off); n2 += __shfl_down(n2, off); }
     __shared__ double sd[4], sn[4];
     int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sd[w] = d2; sn[w] = n2; }
     __syncthreads();
-    if (threadIdx.x == 0 && (int64_t)blockIdx.x * blockDim.x < (int64_t)nnz) {
-        atomicAdd(&acc[0], sd[0] + sd[1] + sd[2] + sd[3]);
-        atomicAdd(&acc[1], sn[0] + sn[1] + sn[2] + sn[3]);
+    if (threadIdx.x == 0) {   // one pair of atomics per block (the grid is a few thousand blocks: same-address atomics serialise)
+        const double bd = sd[0] + sd[1] + sd[2] + sd[3], bn = sn[0] + sn[1] + sn[2] + sn[3];
+        if (bd != 0.0) atomicAdd(&acc[0], bd);
+        if (bn != 0.0) atomicAdd(&acc[1], bn);
     }
 }
 
@@ -2778,6 +2793,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
         return ok;
     };
     const int32_t nwork = *workcount;
+    unsigned long long live_acc = 0ull;   // lane 0: live entries seen by this workgroup (one atomic at the end, spread over LIVE_SLOTS counters)
     for (int32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const int32_t i = worklist[wi];   // lists are filled with atomics: heavy columns end up spread over the grid
         const int32_t v = (int32_t)order[i];
@@ -2799,7 +2815,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
                 serial_order(Ag, B, m, v, 1, D.vbase);
                 for (int j = 0; j < m; ++j) { tmp_nbr[toff + j] = B.a_nbr[j]; tmp_val[toff + j] = B.a_val[j]; }
                 cnt_out[i] = m;
-                atomicAdd(live_total, (unsigned long long)len0);
+                live_acc += (unsigned long long)len0;
                 }
             }
             __syncthreads();
@@ -2916,34 +2932,43 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             tmp_nbr[toff + j] = L.b_nbr[x];
             tmp_val[toff + j] = L.b_val[x];
         }
-        if (lane == 0) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)len0); }
+        if (lane == 0) { cnt_out[i] = m; live_acc += (unsigned long long)len0; }
         __syncthreads();
     }
+    if (lane == 0 && live_acc) atomicAdd(&live_total[(blockIdx.x & (LIVE_SLOTS - 1)) * LIVE_STRIDE], live_acc);
 }
 
 // work lists per capacity tier (5: <=32 (two columns per wave), 0: <=64, 1: <=192, 2: <=512 and what the long-column kernels
 // do not take, 3: k_sc_merge_big, 4: k_sc_merge_huge)
-__global__ __launch_bounds__(256) void k_sc_tierlists(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+__global__ __launch_bounds__(1024) void k_sc_tierlists(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
+    __shared__ int32_t s_cnt[6], s_base[6];
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tier = -1;
     (void)keyed;
+    if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     if (i < S) {
         int32_t e = ext[i];
         tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= HUGECAP) ? (e <= BIGCAP ? 3 : 4) : 2));
     }
-    // one atomic per wave and tier: neighbouring columns stay neighbours in the list (locality of the
-    // staged rows), while the waves' chunks interleave (balance)
+    // one LDS atomic per wave and tier, one global atomic per workgroup and tier (same-address atomics serialise):
+    // neighbouring columns stay neighbours in the list (locality of the staged rows)
+    int32_t my = 0;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
         uint64_t mk = __ballot(tier == t);
         if (mk == 0ull) continue;
         int32_t base = 0;
         const int leader = __builtin_ctzll(mk);
-        if (lane == leader) base = atomicAdd(&counts[t], __popcll(mk));
+        if (lane == leader) base = atomicAdd(&s_cnt[t], __popcll(mk));
         base = __shfl(base, leader);
-        if (tier == t) lists[(size_t)t * S + base + __popcll(mk & lanemask_lt(lane))] = i;
+        if (tier == t) my = base + __popcll(mk & lanemask_lt(lane));
     }
+    __syncthreads();
+    if (threadIdx.x < 6 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (tier >= 0) lists[(size_t)tier * S + s_base[tier] + my] = i;
 }
 
 // Columns of at most 32 slots (most of them after half the vertices are gone): TWO per wave, one per half-wave, entirely
@@ -2963,6 +2988,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const GraphDesc*
     const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
     const bool desc = (A.o_n == ON_DESC) && !keyed;
     const int32_t nwork = *workcount;
+    unsigned long long live_acc = 0ull;   // lanes 0 and 32
     auto to_lane = [&](int target, int v) { return __builtin_amdgcn_ds_permute((gbase + target) << 2, v); };   // forward permute inside the half
     auto to_lane_d = [&](int target, double v) {
         const long long b = __double_as_longlong(v);
@@ -3059,26 +3085,50 @@ __global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const GraphDesc*
             if (have && ok && gl < m) { tmp_nbr[toff + pos] = nbo; tmp_val[toff + pos] = vo; }
         }
         if (have && gl == 0) {
-            if (ok) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)nlive); }
+            if (ok) { cnt_out[i] = m; live_acc += (unsigned long long)nlive; }
             else list64[atomicAdd(count64, 1)] = i;   // depth limit hit: the 64-entry kernel (launched after this one) takes it
         }
     }
+    live_acc += __shfl_down(live_acc, 32);
+    if (lane == 0 && live_acc) atomicAdd(&live_total[(blockIdx.x & (LIVE_SLOTS - 1)) * LIVE_STRIDE], live_acc);
 }
 
-void launch_sc_merge(hipStream_t stream, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
+void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
-                     unsigned long long* live_total, int32_t* lists, int32_t* counts) {
+                     unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* biglists, uint16_t* hugelists) {
     const int keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) ? 1 : 0;
-    hipLaunchKernelGGL(k_sc_tierlists, dim3((S + 255) / 256), dim3(256), 0, stream, ext, S, keyed, lists, counts);
+    hipStream_t stream = X.main;
+    hipLaunchKernelGGL(k_sc_tierlists, dim3((S + 1023) / 1024), dim3(1024), 0, stream, ext, S, keyed, lists, counts);
+    // the tiers are independent of each other (only the <=64 kernel follows the <=32 one, which hands it the columns whose sort
+    // hit the depth limit): the long-column kernels and the LDS tiers run beside the two big tiers on side streams
+    const bool fork = X.side[0] && X.side[1];
+    hipStream_t s1 = fork ? X.side[0] : stream, s2 = fork ? X.side[1] : stream;
+    if (fork) {
+        (void)hipEventRecord(X.ev[0], stream);
+        (void)hipStreamWaitEvent(s1, X.ev[0], 0);
+        (void)hipStreamWaitEvent(s2, X.ev[0], 0);
+    }
+    // long columns: whole column in LDS, one single-wave workgroup each; longer than the LDS record array (hubs of
+    // weighted graphs): records in global scratch, a few workgroups
+    hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s1, A, gd, vgraph, order, ext, tmp_off, lists + 3 * (size_t)S, counts + 3,
+                       tmp_nbr, tmp_val, cnt_out, live_total, biglists);
+    hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s1, A, gd, vgraph, order, ext, tmp_off, lists + 4 * (size_t)S, counts + 4,
+                       tmp_nbr, tmp_val, cnt_out, live_total, hugelists, SS.rec, SS.top, SS.cap, SS.flags);
+    unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
+    unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
+    hipLaunchKernelGGL((k_sc_merge_t<192, 64>), dim3(g1), dim3(64), 0, s2, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + (size_t)S, counts + 1);
+    hipLaunchKernelGGL((k_sc_merge_t<SCAP, 192>), dim3(g2), dim3(64), 0, s2, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + 2 * (size_t)S, counts + 2);
     unsigned gh = (unsigned)(S < 256 * 32 * 4 ? (S + 1) / 2 : 256 * 32 * 4);
     if (gh == 0) gh = 1;
     hipLaunchKernelGGL(k_sc_merge_half, dim3(gh), dim3(64), 0, stream, A, gd, vgraph, order, tmp_off, tmp_nbr, tmp_val, cnt_out, live_total, lists + 5 * (size_t)S, counts + 5, lists, counts);
     unsigned g0 = (unsigned)(S < 256 * 32 * 4 ? S : 256 * 32 * 4);
-    unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
-    unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
     hipLaunchKernelGGL((k_sc_merge_t<64, -1>), dim3(g0), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists, counts);
-    hipLaunchKernelGGL((k_sc_merge_t<192, 64>), dim3(g1), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + (size_t)S, counts + 1);
-    hipLaunchKernelGGL((k_sc_merge_t<SCAP, 192>), dim3(g2), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + 2 * (size_t)S, counts + 2);
+    if (fork) {
+        (void)hipEventRecord(X.ev[1], s1);
+        (void)hipEventRecord(X.ev[2], s2);
+        (void)hipStreamWaitEvent(stream, X.ev[1], 0);
+        (void)hipStreamWaitEvent(stream, X.ev[2], 0);
+    }
 }
 
 // Long columns (SCAP < extent <= BIGCAP): one single-wave workgroup per column with the whole
@@ -3114,6 +3164,7 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     const int32_t nbig = *count;
+    unsigned long long live_acc = 0ull;
     for (int32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         const int32_t i = list[bi];
         const int32_t v = (int32_t)order[i];
@@ -3190,9 +3241,10 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
         else wave_std_sort<Rec2>(R, m, Rec2GreaterB(), WP, lane);   // :331-338
         __syncthreads();
         for (int32_t j = lane; j < m; j += 64) { tmp_nbr[toff + j] = (int32_t)R[j].a; tmp_val[toff + j] = R[j].b; }
-        if (lane == 0) { cnt_out[i] = m; atomicAdd(live_total, (unsigned long long)len0); }
+        if (lane == 0) { cnt_out[i] = m; live_acc += (unsigned long long)len0; }
         __syncthreads();
     }
+    if (lane == 0 && live_acc) atomicAdd(&live_total[(blockIdx.x & (LIVE_SLOTS - 1)) * LIVE_STRIDE], live_acc);
 }
 
 __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
