@@ -424,9 +424,9 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     if (ES.prof) {
         long long pr[40];
         HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
-        const char* names[19] = {"P0 select", "P1 permute + closing barrier", "P1b multi-edge cut + P2 offsets", "P3 sample", "P4 replay", "single path", "P5b slots + shared targets", "move order", "pushes", "P1 meta + loads + dependence", "P5a cursors + pool", "P5c rewire stores", "P1 id rank", "P1 (sync)", "P1 o_n order (sorts)", "P1 write pass", "P1 (sync)", "P1 o_n rank", "empty (cost of one stamp)"};
+        const char* names[20] = {"P0 select", "P1 permute + closing barrier", "P1b multi-edge cut + P2 offsets", "P3 sample", "P4 replay", "single path", "P5b slots + shared targets", "move order", "pushes", "P1 meta + loads + dependence", "P5a cursors + pool", "P5c rewire stores", "P1 id rank", "P1 (sync)", "P1 o_n order (sorts)", "P1 write pass", "P1 (sync)", "P1 o_n rank", "empty (cost of one stamp)", "P3b dependent candidates (patch)"};
         std::fprintf(stderr, "[rlap phase profile] rounds=%lld singles=%lld (100 MHz ticks); shader clock over the kernel: %.0f MHz\n", pr[22], pr[23], pr[21] > 0 ? 100.0 * (double)pr[20] / (double)pr[21] : 0.0);
-        for (int k = 0; k < 19; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
+        for (int k = 0; k < 20; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
         const char* wnames[9] = {"gather", "sort by id", "merge", "meta loads + order", "cumsum + recurrence", "sample", "replay + slots", "rewire", "pq commit"};
         for (int k = 0; k < 9; ++k) std::fprintf(stderr, "  single/wave: %-20s %10.3f ms\n", wnames[k], pr[24 + k] / 1e5);
     }

@@ -638,7 +638,8 @@ struct Ent {
     int32_t nbr;
     int32_t twin;
 };
-enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8, CF_TIE = 16, CF_NEQ = 32, CF_READY = 64 };
+enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8, CF_TIE = 16, CF_NEQ = 32, CF_READY = 64, CF_PATCHED = 128 };
+constexpr int DEPMAX = 4;   // dependent candidates with more earlier neighbours in the round than this cut it
 enum { TF_CONTENDED = 1 };
 
 // BC = live entries a candidate may hold (32: one half-wave per candidate, 64: one wave).
@@ -661,8 +662,10 @@ struct CandT : CandPad<BC> {
     int32_t nmv;      // PQ moves this candidate causes (counted during the replay; bounds the round's move list)
     int32_t nkill;    // merged multi-edges (o_v = random, 64-slot form): e[m .. m+nkill) hold the twins that die (:289)
     int32_t cb[BC <= 32 ? 3 : 4];   // bases of the appended chunks
+    int32_t ndep;     // earlier candidates of the round this one is adjacent to (cand_patch), at most DEPMAX
+    uint8_t dep[4];
     int64_t draw0;    // first uniform
-};   // 864 B (BC=32) / 1680 B (BC=64): word strides 216 / 420
+};   // 872 B (BC=32) / 1688 B (BC=64): word strides 218 / 422
 typedef CandT<BCAP> Cand;
 
 RLAP_HD TRes& ent_tres(Ent& e) { return e.res; }
@@ -716,7 +719,7 @@ RLAP_HD bool cand_merges_multi_edges(const Arrays& A) { return CT::CAP == 64 && 
 // threads: cand_meta (one per candidate), cand_load (one per slot), cand_finish.
 template <class CT>
 RLAP_HD void cand_meta(const Arrays& A, int32_t v, CT& C) {
-    C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0; C.nkill = 0; C.nmv = 0;
+    C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0; C.nkill = 0; C.nmv = 0; C.ndep = 0;
     int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
     int32_t acnt = A.app_cnt[v];
     int32_t base = A.app_chunk[v];              // read with the counts (not after them): one dependent round trip less
@@ -784,6 +787,48 @@ RLAP_HD void cand_prepare(const Arrays& A, int32_t v, CT& C, int32_t vbase = 0) 
     cand_meta(A, v, C);
     for (int32_t e = 0; e < C.ext; ++e) cand_load(A, C, e);
     cand_finish(A, C, vbase);
+}
+
+// A candidate d adjacent to an EARLIER candidate j of the same round sees j eliminated first (preconditioner.cc:404-414):
+// with d at position p of j's order, the twin of j's entry -- d's entry towards j -- is rewritten in place to
+// (k, w_new) where k is the neighbour j sampled for position p, and its twin becomes the entry j appends to k's column.
+// That is all that happens to d as long as d is neither sampled as a target by j (it would get an appended entry and an
+// Inc: it leaves the predicted order) nor j's last neighbour (its entry dies, Dec: it pre-empts the order) and as long as
+// k is not a neighbour of d already (a multi-edge: the PQ orders send those to the single-vertex path).  Then d's
+// record can be patched from j's sampled record without touching memory; the number of neighbours, hence the number of
+// uniforms d draws, is unchanged.  The twin is recorded as ~(j * CAP + p): resolved from the round's slot table at commit.
+// Sequential form (one thread); returns false when d cannot be patched (the round is cut before it).
+// Must run after every earlier candidate has been sampled (ksel, new weights in e[].val) and before d is.
+template <class CT>
+RLAP_HD bool cand_patch(const Arrays& A, CT* cand, int32_t d, int32_t vbase) {
+    CT& C = cand[d];
+    for (int32_t q = 0; q < C.ndep; ++q) {
+        const int32_t j = C.dep[q];
+        const CT& J = cand[j];
+        int32_t p = -1;
+        for (int32_t z = 0; z < J.m; ++z) if (J.e[z].nbr == C.v) p = z;
+        if (p < 0 || p == J.m - 1) return false;                        // (last neighbour: :420-432)
+        for (int32_t z = 0; z < J.m - 1; ++z) if (J.ksel[z] == p) return false;   // sampled as a target (:394-399)
+        const int32_t k = J.e[J.ksel[p]].nbr;
+        int32_t qd = -1;
+        for (int32_t z = 0; z < C.m; ++z) { if (C.e[z].nbr == J.v) qd = z; if (C.e[z].nbr == k) { C.flags |= CF_DUP; return false; } }
+        if (qd < 0) return false;
+        C.e[qd].nbr = k; C.e[qd].val = J.e[p].val; C.e[qd].twin = ~(j * CT::CAP + p);
+    }
+    C.flags |= CF_PATCHED;
+    // order again: by id (:275; ids are distinct), then by o_n (:295-307) -- as cand_finish does
+    const int32_t len = C.m;
+    gs_std_sort<Ent>(C.e, len, EntLessNbr());
+    if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
+        uint64_t kb = keyed_order_base(A.shuffle_seed, C.v - vbase, 0);
+        for (int32_t i = 0; i < len; ++i) C.e[i].aux = keyed_order_dkey(kb, C.e[i].nbr - vbase);
+        gs_std_sort<Ent>(C.e, len, EntLessAux());
+    } else if (A.o_n == ON_ASC) {
+        gs_std_sort<Ent>(C.e, len, EntLessVal());
+    } else {
+        gs_std_sort<Ent>(C.e, len, EntGreaterVal());
+    }
+    return true;
 }
 
 RLAP_HD int32_t ent_upper_index(const Ent* e, int32_t m, double r) {  // first a with cum[a] > r, else m-1

@@ -1497,6 +1497,75 @@ __device__ __forceinline__ void slots_into_target(const Arrays& A, const CT& C, 
 template <class CT>
 __device__ __noinline__ void cand_order_index_call(const Arrays& A, CT& C) { cand_order_index(A, C); }
 
+// rlap_core.h::cand_patch by one wave (32-slot candidates: one entry per lane of the lower half), followed by the sampling of
+// the patched candidate.  d's entries live in registers while they are patched and ordered again: by id with a rank count
+// (ids are distinct), by o_n with the half-wave std::sort restatement.  Returns false when d cannot be patched.
+template <int ON, class CT>
+__device__ __noinline__ bool wave_patch(const Arrays& A, CT* cand, int32_t d, int32_t vbase, int32_t* tmp_wave) {
+    static_assert(CT::CAP == 32, "one entry per lane of a half-wave");
+    const int lane = lane_id();
+    CT& C = cand[d];
+    const int32_t m = C.m, nd = C.ndep, v = C.v;
+    int32_t my_nbr = lane < m ? C.e[lane].nbr : -1;
+    double my_val = lane < m ? C.e[lane].val : 0.0;
+    int32_t my_twin = lane < m ? C.e[lane].twin : 0;
+    bool ok = true, dup = false;
+    for (int32_t q = 0; q < nd && ok; ++q) {
+        const int32_t j = C.dep[q];
+        const CT& J = cand[j];
+        const int32_t mj = J.m;
+        const int32_t jn = lane < mj ? J.e[lane].nbr : -2;
+        const uint64_t pm = __ballot(jn == v);
+        if (pm == 0ull) { ok = false; break; }
+        const int32_t p = __builtin_ctzll(pm);
+        if (p == mj - 1) { ok = false; break; }                                   // last neighbour (:420-432)
+        const int32_t ks = lane < mj - 1 ? (int32_t)J.ksel[lane] : -1;
+        if (__ballot(ks == p) != 0ull) { ok = false; break; }                     // sampled as a target (:394-399)
+        const int32_t k = J.e[J.ksel[p]].nbr;
+        const double newv = J.e[p].val;
+        if (__ballot(my_nbr == k) != 0ull) { ok = false; dup = true; break; }     // multi-edge: single-vertex path
+        const uint64_t qm = __ballot(my_nbr == J.v);
+        if (qm == 0ull) { ok = false; break; }
+        if (lane == __builtin_ctzll(qm)) { my_nbr = k; my_val = newv; my_twin = ~(j * CT::CAP + p); }
+    }
+    if (!ok) {
+        if (lane == 0 && dup) atomicOr(&C.flags, CF_DUP);
+        return false;
+    }
+    // order by id (:275): rank = smaller ids (distinct)
+    int32_t rank = 0;
+    for (int32_t q = 0; q < m; ++q) { const int32_t nq = __shfl(my_nbr, q); rank += (nq < my_nbr) ? 1 : 0; }
+    {
+        const int target = lane < m ? rank : lane;
+        my_nbr = __builtin_amdgcn_ds_permute(target << 2, my_nbr);
+        my_twin = __builtin_amdgcn_ds_permute(target << 2, my_twin);
+        const long long bv = __double_as_longlong(my_val);
+        const int lo = __builtin_amdgcn_ds_permute(target << 2, (int)(uint32_t)bv), hi = __builtin_amdgcn_ds_permute(target << 2, (int)(uint32_t)((unsigned long long)bv >> 32));
+        my_val = __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+    }
+    // order by o_n (:295-307) with std::sort semantics
+    constexpr bool keyed = (ON == ON_RANDOM);
+    double key = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, v - vbase, 0), my_nbr - vbase) : my_val;
+    int idx = lane & 31, pos = lane & 31;
+    const bool want = lane < 32 && m > 1;
+    const bool okg = (ON == ON_DESC) ? group_sort<true, 32>(key, idx, m, want, lane, tmp_wave, &pos) : group_sort<false, 32>(key, idx, m, want, lane, tmp_wave, &pos);
+    if (__ballot(want && !okg) != 0ull) return false;   // depth limit of the introsort: leave it to the single-vertex path (conservative)
+    {
+        const int32_t nb = __shfl(my_nbr, idx), tw = __shfl(my_twin, idx);
+        const double vv = __shfl(my_val, idx);
+        WAVE_SYNC();
+        if (lane < m) { Ent& E = C.e[pos]; E.nbr = nb; E.twin = tw; E.val = vv; E.aux = 0; }
+    }
+    WAVE_SYNC();
+    // sampling of the patched candidate (P3 of the round, for this one candidate)
+    if (lane == 0) cand_cumsum(A, C);
+    WAVE_SYNC();
+    if (lane < m - 1) cand_pick(A, C, lane);
+    if (lane == 63) cand_recur(A, C);
+    WAVE_SYNC();
+    return true;
+}
+
 __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G, const ElimScratch& S, int32_t v0, int64_t e1) {
     ColBuf Bf = S.colbuf(G.scr_base);
     int rc = serial_eliminate(A, G, Bf, G.scr_cap, v0, e1);
@@ -1522,6 +1591,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     typedef CandT<BC> Cand;
     typedef BatchLdsT<BC, NTT> BatchLds;
     constexpr bool MERGE = (BC == 64 && OV == OV_RANDOM);           // multi-edges merged inside the candidate (rlap_core.h::cand_merges_multi_edges)
+    constexpr bool PATCH = (BC == 32 && OV == OV_DEGREE);           // candidates adjacent to earlier ones of the round are patched in LDS (rlap_core.h::cand_patch)
     constexpr int GSH = 64 - BC;                                  // lane & GSH = first lane of my group
     constexpr uint64_t GMASK = BC == 64 ? ~0ull : 0xFFFFFFFFull;   // a group's part of a 64-bit ballot
     Arrays A = A_in;
@@ -1530,7 +1600,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     A.shuffle_seed = A_in.shuffle_seed + (uint64_t)blockIdx.x;   // graph g of a batch: seed + g, ids local to the graph (rlap_core.h)
     __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
-    __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end;
+    __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end, s_anydep, s_npatched;
     constexpr int32_t POOL_GRAB = NT >= 1024 ? POOL_GRAB_BIG : POOL_GRAB_SMALL;   // slots reserved at a time for the round's appends
     __shared__ uint8_t s_eqperm[BC - 16][BC];   // std::sort's permutation of n = 17..BC all-equal keys
     __shared__ uint8_t s_eqinv[BC - 16][BC];    // its inverse: final position of the entry with id-rank r
@@ -1538,7 +1608,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
     if (tid == 0) {
-        G = gd[g]; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0;
+        G = gd[g]; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0; s_anydep = 0; s_npatched = 0;
         // the input checks of the setup kernels are read here, not on the host (no mid-call synchronisation): bad input -> nothing is eliminated
         int32_t bad = 0;
         if (in_flags[FLAG_RANGE]) bad = ST_INDEX_RANGE;
@@ -1745,7 +1815,14 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t i = (k * NT + tid) / BCAP;
-                if (bpk[k] >= 0 && bpk[k] < i) atomicMin(&s_pmax, i);
+                if (bpk[k] >= 0 && bpk[k] < i) {
+                    if (PATCH) {
+                        // adjacent to an earlier candidate of the round: remembered, patched after that one is sampled (wave_patch)
+                        const int32_t q = atomicAdd(&L.cand[i].ndep, 1);
+                        if (q < DEPMAX) L.cand[i].dep[q] = (uint8_t)bpk[k]; else atomicMin(&s_pmax, i);
+                        s_anydep = 1;
+                    } else atomicMin(&s_pmax, i);
+                }
             }
             if (tid < nc && (L.cand[tid].flags & CF_BIG)) atomicMin(&s_pmax, tid);
             __syncthreads();
@@ -2027,7 +2104,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         int dtot;
         const int dex = block_excl_scan<NWAVE>((tid < nc && !first_is_big) ? L.cand[tid].ndraw : 0, L.scan, &dtot);
         __syncthreads();
-        const int32_t Pmax = first_is_big ? 0 : (s_pmax < nc ? s_pmax : nc);
+        int32_t Pmax = first_is_big ? 0 : (s_pmax < nc ? s_pmax : nc);
         int32_t P = 0;
         PHASE_STAMP(2);
         if (Pmax > 0) {
@@ -2036,21 +2113,58 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             // ================= P3: sampling =================
             if (tid < Pmax) {
                 L.cand[tid].draw0 = G.n_draws + dex;
-                cand_cumsum(A, L.cand[tid]);
+                if (!PATCH || L.cand[tid].ndep == 0) cand_cumsum(A, L.cand[tid]);
             }
             __syncthreads();
             if (A.o_v != OV_COARSEN) {
                 #pragma unroll 1
                 for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
                     const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
-                    if (i >= Pmax) continue;
+                    if (i >= Pmax || (PATCH && L.cand[i].ndep != 0)) continue;
                     if (j < L.cand[i].m - 1) cand_pick(A, L.cand[i], j);
                 }
                 // the recurrence (touches e[].val only) runs on the LAST waves, whose share of the picks above is
                 // empty unless the round is nearly full: it overlaps with the other waves' picks
-                if (tid >= NT - BATCH && tid - (NT - BATCH) < Pmax) cand_recur(A, L.cand[tid - (NT - BATCH)]);
+                if (tid >= NT - BATCH && tid - (NT - BATCH) < Pmax && (!PATCH || L.cand[tid - (NT - BATCH)].ndep == 0)) cand_recur(A, L.cand[tid - (NT - BATCH)]);
             }
             __syncthreads();
+            PHASE_STAMP(3);
+            if constexpr (PATCH) { if (s_anydep) {
+                // ---- dependent candidates: patched from the sampled records of the earlier candidates they are adjacent to, ordered
+                //      again and sampled, one wave each; a candidate waits until the ones it depends on are through (a chain of
+                //      dependent candidates takes one pass of this loop per link).  What cannot be patched cuts the round. ----
+                int32_t* const ptmp = reinterpret_cast<int32_t*>(L.cont) + (tid >> 6) * 160;   // the record lists are idle until the replay
+                static_assert(sizeof(CRec) * CCAP * 2 >= (size_t)NWAVE * 160 * 4, "sort scratch of the patching waves fits the record lists");
+                int32_t Pcur = Pmax;
+                while (true) {
+                    bool progress = false;
+                    #pragma unroll 1
+                    for (int32_t i = (tid >> 6); i < Pcur; i += NWAVE) {
+                        Cand& C = L.cand[i];
+                        const int32_t nd = C.ndep;
+                        if (nd == 0 || (C.flags & (CF_PATCHED | CF_DEP))) continue;     // (wave-uniform)
+                        bool ready = true, lost = false;
+                        for (int32_t q = 0; q < nd && q < DEPMAX; ++q) {
+                            const Cand& J = L.cand[C.dep[q]];
+                            if (J.ndep != 0) { if (J.flags & CF_DEP) lost = true; else if (!(J.flags & CF_PATCHED)) ready = false; }
+                        }
+                        if (lost) { if (lane == 0) { atomicOr(&C.flags, CF_DEP); atomicMin(&s_pmax, i); } progress = true; continue; }   // behind a cut
+                        if (!ready) continue;
+                        Arrays A3 = A;
+                        const bool okp = wave_patch<ON>(A3, L.cand, i, G.vbase, ptmp);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) {
+                            if (okp) { atomicOr(&C.flags, CF_PATCHED); s_npatched = 1; }
+                            else { atomicOr(&C.flags, CF_DEP); atomicMin(&s_pmax, i); }
+                        }
+                        progress = true;
+                    }
+                    if (!__syncthreads_or(progress ? 1 : 0)) break;
+                    Pcur = s_pmax < Pcur ? s_pmax : Pcur;
+                }
+                Pmax = s_pmax < Pmax ? s_pmax : Pmax;
+            } }
+            PHASE_STAMP(19);
             PHASE_STAMP(3);
             // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
             int32_t key0k[PASSES];   // the targets' keys: fetched here, used after the barrier (their latency hides behind the table)
@@ -2187,7 +2301,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr);
                 }
             }
-            if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; }
+            if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_anydep = 0; s_npatched = 0; }
             __syncthreads();
             if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
             done += 1;
@@ -2205,7 +2319,10 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             Cand& C = L.cand[tid];
             if (use_pq) A.pqpos[C.v] = -2;
             // the edge to the last neighbour (or to the coarsening target) dies (:429-430 | :880-881)
-            if (C.m >= 1) A.e_val[C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin] = 0;
+            if (C.m >= 1) {
+                const int32_t tw = C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin;
+                if (!PATCH || tw >= 0) A.e_val[tw] = 0;   // (a patched entry's twin is appended in this very round: second pass of the rewire stores)
+            }
             if (MERGE) for (int32_t q = 0; q < C.nkill; ++q) A.e_val[C.e[C.m + q].twin] = 0;   // merged multi-edges (:289)
         }
         // append cursors of the targets shared by several candidates: loaded now (one group head per thread), used
@@ -2358,7 +2475,24 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 const bool co = A.o_v == OV_COARSEN;
                 if (co ? (pp < C.m && pp != C.koff) : (pp < C.m - 1)) {
                     const int32_t kk = co ? C.koff : (int32_t)C.ksel[pp];
-                    rewire_store(A, C.e[pp].twin, L.pslot[i * BCAP + pp], C.e[pp].nbr, C.e[kk].nbr, C.e[pp].val);
+                    if (!PATCH || C.e[pp].twin >= 0) rewire_store(A, C.e[pp].twin, L.pslot[i * BCAP + pp], C.e[pp].nbr, C.e[kk].nbr, C.e[pp].val);
+                }
+            }
+        }
+        if (PATCH && s_npatched) {
+            // entries of patched candidates whose twin is an entry an EARLIER candidate of this round appends (~twin = its place in the
+            // slot table): that candidate's stores (first pass, above) come first, the rewrite in place (:404-406) or the kill (:429-430) second
+            __syncthreads();
+#pragma unroll 1
+            for (int k = 0; k < PASSES; ++k) {
+                const int32_t i = tid / (NT / BATCH), pp = k * (NT / BATCH) + tid % (NT / BATCH);
+                if (i < P) {
+                    const Cand& C = L.cand[i];
+                    if (pp < C.m && C.e[pp].twin < 0) {
+                        const int32_t s_r = L.pslot[~C.e[pp].twin];
+                        if (pp < C.m - 1) rewire_store(A, s_r, L.pslot[i * BCAP + pp], C.e[pp].nbr, C.e[(int32_t)C.ksel[pp]].nbr, C.e[pp].val);
+                        else A.e_val[s_r] = 0;
+                    }
                 }
             }
         }
@@ -2611,7 +2745,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         if (tid < nc) batch_pos[L.cand[tid].v] = -1;
         if (tid == 0) {
             G.n_draws = L.cand[P - 1].draw0 + L.cand[P - 1].ndraw;   // offsets are a running sum (P2)
-            s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0;
+            s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_anydep = 0; s_npatched = 0;
         }
         done += P;
         pending_long = (OV == OV_RANDOM) && P < nc && (L.cand[P].flags & CF_BIG) != 0;

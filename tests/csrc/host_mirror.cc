@@ -137,6 +137,9 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
     typedef CandT<BC> Cand;
     std::vector<Cand> cand((size_t)Bsz);
     int64_t why[6] = {0, 0, 0, 0, 0, 0};
+    int64_t adjcase[4] = {0, 0, 0, 0};
+    int64_t npatch_try = 0, npatch_ok = 0;
+    const bool patching = (A.o_v != OV_COARSEN) && (BC == 32) && (std::getenv("RLAP_MIRROR_NO_PATCH") == nullptr);   // first dependent candidate of a round: sampled by an earlier one (moves away), last neighbour (Dec), patchable, patch makes a multi-edge
     int64_t single_len = 0, single_gt384 = 0, single_gt384_len = 0, single_max = 0;  // adjacent, big, dup, complex, pre-empted, full
     std::vector<int32_t> batch_pos((size_t)n, -1), tcount((size_t)n, 0);
     struct CRec { int32_t x, i, j; };
@@ -173,11 +176,17 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
         // ---- P1: prepare (thread per candidate) ----
         for (int32_t i = 0; i < nc; ++i) { int32_t v = cand[i].v, src = cand[i].src; cand_prepare(A, v, cand[i]); cand[i].src = src; batch_pos[v] = i; }
         // ---- P1b: dependence; Pmax ----
+        // A candidate adjacent to EARLIER candidates of the round ("dependent") no longer cuts the round by itself: its
+        // record is patched from theirs once they are sampled (cand_patch).  It still cuts when it has more than DEPMAX of them.
         int32_t Pmax = nc; int Pwhy = 5;
         for (int32_t i = 0; i < nc; ++i) {
             Cand& C = cand[i];
             bool bad = (C.flags & (CF_BIG | CF_DUP)) != 0;
-            if (!bad) for (int32_t j = 0; j < C.m; ++j) { int32_t bp = batch_pos[C.e[j].nbr]; if (bp >= 0 && bp < i) { bad = true; break; } }
+            C.ndep = 0;
+            if (!bad) for (int32_t j = 0; j < C.m; ++j) {
+                int32_t bp = batch_pos[C.e[j].nbr];
+                if (bp >= 0 && bp < i) { if (!patching || C.ndep >= DEPMAX) { bad = true; break; } C.dep[C.ndep++] = (uint8_t)bp; }
+            }
             if (bad && i < Pmax) { Pmax = i; Pwhy = (C.flags & CF_BIG) ? 1 : (C.flags & CF_DUP) ? 2 : 0; }
         }
         auto consume = [&](int32_t P) {   // candidates [0,P) leave the queue
@@ -205,8 +214,34 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
         int64_t off = G.n_draws;
         for (int32_t i = 0; i < Pmax; ++i) { cand[i].draw0 = off; off += cand[i].ndraw; }
         if (off > A.rng_len) return ST_RNG_OVERFLOW;
-        // ---- P3: sampling ----
-        for (int32_t i = 0; i < Pmax; ++i) cand_sample(A, cand[i]);
+        // ---- P3: sampling; dependent candidates are patched first (their earlier neighbours are sampled by then) ----
+        for (int32_t i = 0; i < Pmax; ++i) {
+            if (cand[i].ndep > 0) {
+                ++npatch_try;
+                if (!cand_patch(A, cand.data(), i, G.vbase)) { Pmax = i; Pwhy = (cand[i].flags & CF_DUP) ? 2 : 0; break; }
+                ++npatch_ok;
+            }
+            cand_sample(A, cand[i]);
+        }
+        if (false && Pwhy == 0 && Pmax < nc && A.o_v != OV_COARSEN) {
+            // what would it take to carry on past the first dependent candidate d = cand[Pmax]?
+            Cand& D = cand[Pmax];
+            bool any_last = false, any_target = false, any_dup = false;
+            for (int32_t q = 0; q < D.m; ++q) {
+                int32_t bp = batch_pos[D.e[q].nbr];
+                if (bp < 0 || bp >= Pmax) continue;
+                Cand& J = cand[bp];
+                int32_t p = -1;
+                for (int32_t z = 0; z < J.m; ++z) if (J.e[z].nbr == D.v) p = z;
+                if (p < 0) continue;
+                if (p == J.m - 1) any_last = true;
+                int32_t c = 0;
+                for (int32_t z = 0; z < J.m - 1; ++z) if (J.ksel[z] == p) ++c;
+                if (c > 0) any_target = true;
+                if (p < J.m - 1) { int32_t k = J.e[J.ksel[p]].nbr; for (int32_t z = 0; z < D.m; ++z) if (D.e[z].nbr == k) any_dup = true; }
+            }
+            ++adjcase[any_last ? 1 : any_target ? 0 : any_dup ? 3 : 2];
+        }
         // ---- P4: PQ replay with contended targets in candidate order ----
         for (int32_t i = 0; i < Pmax; ++i) for (int32_t j = 0; j < cand[i].m; ++j) tcount[cand[i].e[j].nbr]++;
         std::vector<CRec> cont;
@@ -325,11 +360,12 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
             } else {
                 for (int32_t j = 0; j < m - 1; ++j) {
                     int32_t k = C.e[C.ksel[j]].nbr, s_r = C.e[j].twin, s_n = pslot[i][j];
+                    if (s_r < 0) s_r = pslot[(~s_r) / BC][(~s_r) % BC];   // patched entry: the slot an earlier candidate of this round appends
                     double nw = C.e[j].val;
                     A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
                     A.e_nbr[s_n] = C.e[j].nbr; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
                 }
-                if (m >= 1) A.e_val[C.e[m - 1].twin] = 0;
+                if (m >= 1) { int32_t s_l = C.e[m - 1].twin; if (s_l < 0) s_l = pslot[(~s_l) / BC][(~s_l) % BC]; A.e_val[s_l] = 0; }
             }
             for (int32_t q = 0; q < C.nkill; ++q) A.e_val[C.e[m + q].twin] = 0;   // merged multi-edges (:289)
             G.n_draws += C.ndraw;
@@ -340,7 +376,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
         cleanup();
         done += P;
     }
-    if (stats_out) { stats_out[0] = rounds; stats_out[1] = singles; stats_out[2] = contended_total; for (int q = 0; q < 6; ++q) stats_out[3 + q] = why[q]; stats_out[9] = single_len; stats_out[10] = single_gt384; stats_out[11] = single_gt384_len; stats_out[12] = single_max; }
+    if (stats_out) { stats_out[0] = rounds; stats_out[1] = singles; stats_out[2] = contended_total; for (int q = 0; q < 6; ++q) stats_out[3 + q] = why[q]; stats_out[9] = single_len; stats_out[10] = single_gt384; stats_out[11] = single_gt384_len; stats_out[12] = single_max; for (int q = 0; q < 4; ++q) stats_out[13 + q] = adjcase[q]; stats_out[17] = npatch_try; stats_out[18] = npatch_ok; }
     return S.finish(nelim, npop, order_out, out, out_rows);
 }
 

@@ -115,7 +115,7 @@ def _mirror_batch(lib, ei, w, n, t, o_v, o_n, B, perm=None, seed=0, bc=32):
     out = ctypes.POINTER(ctypes.c_double)()
     rows = ctypes.c_int64()
     order = np.full(max(n, 1), -1, dtype=np.int64)
-    stats = np.zeros(13, dtype=np.int64)
+    stats = np.zeros(24, dtype=np.int64)
     p = np.ascontiguousarray(perm, dtype=np.int64) if perm is not None else None
     lib.mirror_approx_chol_batch_bc.restype = ctypes.c_int
     rc = lib.mirror_approx_chol_batch_bc(

@@ -19,4 +19,4 @@ perm = np.random.RandomState(10).permutation(N) if o_v == "random" else None
 t0 = time.time()
 _, _, st = tcm._mirror_batch(lib, ei, None, N, N // 2, o_v, o_n, B, perm=perm, seed=3, bc=bc)
 print(f"{N=} {m=} {o_v}/{o_n} B={B} bc={bc}: rounds={st[0]} singles={st[1]} avgP={(N//2)/st[0]:.2f} contended={st[2]} "
-      f"ended by: adjacent={st[3]} long={st[4]} multi-edge={st[5]} complex={st[6]} pre-empted={st[7]} nothing={st[8]}; singles: avg len {st[9]/max(st[1],1):.0f}, {st[10]} over 384 entries (avg {st[11]/max(st[10],1):.0f}), max {st[12]}  ({time.time()-t0:.1f}s)")
+      f"ended by: adjacent={st[3]} long={st[4]} multi-edge={st[5]} complex={st[6]} pre-empted={st[7]} nothing={st[8]}; singles: avg len {st[9]/max(st[1],1):.0f}, {st[10]} over 384 entries (avg {st[11]/max(st[10],1):.0f}), max {st[12]}; first dependent candidate: sampled-as-target={st[13]} last-neighbour={st[14]} patchable={st[15]} patch-makes-multi-edge={st[16]}  ({time.time()-t0:.1f}s)")
