@@ -5,7 +5,7 @@
 # 2. --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes  -> HBM-side traffic per kernel
 # 3. --pmc SQ_* on the same command                        -> issue / wait picture of the elimination kernel
 # Raw outputs land in gpurun_out/prof_<round>/ ; tools/profile_summarize.py condenses them into profiles/.
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT

@@ -79,7 +79,13 @@ def pick(prefix):
     return {"fetch_bytes": fb, "write_bytes": wb}
 
 
+import hashlib
+_h = hashlib.sha256()
+for _f in ("rlap_kernels.hip", "rlap_core.h", "rlap_api.hip"):
+    _h.update(open(os.path.join(ROOT, "rlap_amd", "csrc", _f), "rb").read())
 traffic = {
+    "_kernels_sha": _h.hexdigest()[:16],   # bench.py reports these figures only while the kernel sources are the profiled ones
+    "_commit": os.environ.get("RLAP_COMMIT"),
     "_source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline`, "
                f"profiles/{rnd}_pmc_fetch_write_bench_c3.csv; bytes = KB*1024, summed over the instantiations of a kernel; FETCH_SIZE is uncorrected "
                "(gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section; narrower accesses uncalibrated)",
