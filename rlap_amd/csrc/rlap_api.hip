@@ -57,7 +57,7 @@ struct rlap_handle_s {
     // setup
     DevBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, permchk, genperm;
     // graph state
-    DevBuf e_nbr, e_val, e_twin, app_cnt, app_chunk, key, pqpos, ocur, oend, origpos, orig_order, gd_d, pool_top;
+    DevBuf ent, vrec, ocur, oend, origpos, orig_order, gd_d, pool_top;
     DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, prof;
     DevBuf skey0, skey1, sval0, sval1;
     DevBuf rng;
@@ -218,11 +218,11 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     ENSURE(h->keys0, 8 * Ealloc); ENSURE(h->keys1, 8 * Ealloc);
     ENSURE(h->idx0, 4 * Ealloc); ENSURE(h->idx1, 4 * Ealloc);
     ENSURE(h->head, 4 * (Ealloc + 1)); ENSURE(h->pos, 4 * (Ealloc + 1));
-    ENSURE(h->e_nbr, 4 * slot_cap); ENSURE(h->e_val, 8 * slot_cap); ENSURE(h->e_twin, 4 * slot_cap);
+    ENSURE(h->ent, sizeof(Slot) * slot_cap);
     ENSURE(h->slot_col, 4 * Ealloc);
     ENSURE(h->colptr, 4 * (N + 1));
     ENSURE(h->gd_d, sizeof(GraphDesc) * G);
-    ENSURE(h->app_cnt, 4 * N); ENSURE(h->app_chunk, 4 * N); ENSURE(h->key, 4 * N); ENSURE(h->pqpos, 4 * N);
+    ENSURE(h->vrec, sizeof(VRec) * N);
     ENSURE(h->origpos, 4 * N);
     ENSURE(h->ocur, 4 * bucket_total); ENSURE(h->oend, 4 * bucket_total);
     ENSURE(h->bs_cnt, 4 * bucket_total); ENSURE(h->bs_alloc, 4 * bucket_total); ENSURE(h->bs_dir, 4 * bucket_total * BDIR);
@@ -292,28 +292,27 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(nnz_p, h->pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), h->idx1.as<uint32_t>(), h->head.as<int32_t>(),
-                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
-                           h->slot_col.as<int32_t>());
+                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, h->ent.as<Slot>(), h->slot_col.as<int32_t>());
     }
     hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, h->slot_col.as<int32_t>(), nnz_p, (int32_t)N, h->colptr.as<int32_t>());
     if (Eeff > 0)
-        hipLaunchKernelGGL(k_twin_sym, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->e_nbr.as<int32_t>(), h->e_val.as<double>(),
-                           h->slot_col.as<int32_t>(), nnz_p, h->e_twin.as<int32_t>(), acc);
+        hipLaunchKernelGGL(k_twin_sym, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->ent.as<Slot>(),
+                           h->slot_col.as<int32_t>(), nnz_p, acc);
     HIPCHK(hipMemcpyAsync(h->pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
     // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)
     hipLaunchKernelGGL(k_gd_scratch, dim3(1), dim3(256), 0, s, h->colptr.as<int32_t>(), h->node_ptr_d.as<int64_t>(), (int32_t)G, h->gd_d.as<GraphDesc>());
 
     // ---------------- PQ init ----------------
     const unsigned gbits = bits_for((uint64_t)(G > 0 ? G - 1 : 0));
-    hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->vgraph.as<int32_t>(), (int32_t)N, h->key.as<int32_t>(),
-                       h->pqpos.as<int32_t>(), h->app_cnt.as<int32_t>(), h->app_chunk.as<int32_t>(), h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
+    hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->vgraph.as<int32_t>(), (int32_t)N, h->vrec.as<VRec>(),
+                       h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
     {
         // key = graph << 32 | degree: only the bits that can be set take part in the sort
         int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 32 + gbits);
         if (rc) return rc;
     }
     HIPCHK(hipMemcpyAsync(h->orig_order.p, h->sval1.p, 4 * N, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, h->orig_order.as<uint32_t>(), h->key.as<int32_t>(), h->vgraph.as<int32_t>(),
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, h->orig_order.as<uint32_t>(), h->vrec.as<VRec>(), h->vgraph.as<int32_t>(),
                        h->gd_d.as<GraphDesc>(), (int32_t)N, h->ocur.as<int32_t>(), h->oend.as<int32_t>(), h->origpos.as<int32_t>());
 
     // ---------------- o_v = random: the node_id vector ----------------
@@ -337,10 +336,9 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
 
     Arrays A;
     A.colptr = h->colptr.as<int32_t>();
-    A.e_nbr = h->e_nbr.as<int32_t>(); A.e_val = h->e_val.as<double>(); A.e_twin = h->e_twin.as<int32_t>();
+    A.e = h->ent.as<Slot>();
     A.slot_cap = (int32_t)slot_cap; A.pool_top = h->pool_top.as<int32_t>();
-    A.app_cnt = h->app_cnt.as<int32_t>(); A.app_chunk = h->app_chunk.as<int32_t>();
-    A.key = h->key.as<int32_t>(); A.pqpos = h->pqpos.as<int32_t>();
+    A.vr = h->vrec.as<VRec>();
     A.ocur = h->ocur.as<int32_t>(); A.oend = h->oend.as<int32_t>();
     A.orig_order = h->orig_order.as<int32_t>();
     A.bs_cnt = h->bs_cnt.as<int32_t>(); A.bs_alloc = h->bs_alloc.as<int32_t>(); A.bs_dir = h->bs_dir.as<int32_t>();
@@ -371,7 +369,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
                            h->surv_base_d.as<int64_t>(), (int32_t)N, h->sval1.as<uint32_t>());
         order = h->sval1.as<uint32_t>();
     } else {
-        hipLaunchKernelGGL(k_sc_keys, dim3(nblk(N, 256)), dim3(256), 0, s, h->key.as<int32_t>(), h->pqpos.as<int32_t>(), h->origpos.as<int32_t>(),
+        hipLaunchKernelGGL(k_sc_keys, dim3(nblk(N, 256)), dim3(256), 0, s, h->vrec.as<VRec>(), h->origpos.as<int32_t>(),
                            h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N, h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
         // key = bucket << 32 | order, all ones for eliminated vertices
         int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 64);
@@ -379,7 +377,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         order = h->sval1.as<uint32_t>();
     }
     if (S > 0)
-        hipLaunchKernelGGL(k_sc_ext, dim3(nblk(S, 256)), dim3(256), 0, s, order, h->colptr.as<int32_t>(), h->app_cnt.as<int32_t>(), (int32_t)S, h->ext.as<int32_t>());
+        hipLaunchKernelGGL(k_sc_ext, dim3(nblk(S, 256)), dim3(256), 0, s, order, h->colptr.as<int32_t>(), h->vrec.as<VRec>(), (int32_t)S, h->ext.as<int32_t>());
     { int rc = excl_scan(h, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), S + 1); if (rc) return rc; }
     ScScratch SS;
     SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = scr_budget; SS.top = counters + 0; SS.flags = flags;
@@ -510,7 +508,7 @@ int rlap_create(rlap_handle* out) {
 int rlap_destroy(rlap_handle h) {
     if (!h) return RLAP_OK;
     DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->scal, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
-                      &h->deg, &h->colptr, &h->slot_col, &h->permchk, &h->genperm, &h->e_nbr, &h->e_val, &h->e_twin, &h->app_cnt, &h->app_chunk, &h->key, &h->pqpos,
+                      &h->deg, &h->colptr, &h->slot_col, &h->permchk, &h->genperm, &h->ent, &h->vrec,
                       &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
                       &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
                       &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->biglist, &h->biglists, &h->hugelists, &h->results};

@@ -317,13 +317,26 @@ struct ColBuf {         // working storage for one column (LDS or global scratch
     int32_t* ksel; int32_t* t_key; int32_t* t_mv; int32_t* t_of;  // t_of[j] = b-index of final position j
 };
 
+// One directed entry = one 16-byte record: a candidate's gather is one load per slot and a rewire one store per slot
+// (round 1 kept three arrays: three 64-byte lines touched per slot).
+struct alignas(16) Slot {
+    double val;     // weight; <= 0: dead (never unlinked, like the reference's nodes)
+    int32_t nbr;    // neighbour (global id); in a chunk header: base of the previous chunk
+    int32_t twin;   // slot of the transposed entry
+};
+// Per-vertex state in one 16-byte record: what a round reads about a candidate or a sampled target sits in one line.
+struct alignas(16) VRec {
+    int32_t key;        // PQ key (degree proxy, preconditioner.cc:125-246)
+    int32_t pqpos;      // -1 = original place, >= 0 id of its latest push, -2 popped
+    int32_t app_cnt;    // appended entries
+    int32_t app_chunk;  // base of the newest chunk (-1: none)
+};
 struct Arrays {
     const int32_t* colptr;   // [N+1]
-    int32_t* e_nbr; double* e_val; int32_t* e_twin;  // [slot_cap]; slots [0,nnz) = CSR, rest = chunk pool
+    Slot* e;                 // [slot_cap]; slots [0,nnz) = CSR, rest = chunk pool
     int32_t slot_cap;
     int32_t* pool_top;       // next free slot (device counter)
-    int32_t* app_cnt; int32_t* app_chunk;            // [N]
-    int32_t* key; int32_t* pqpos;                    // [N]; pqpos -1 = original place, >=0 log entry, -2 popped
+    VRec* vr;                // [N]
     int32_t* ocur; int32_t* oend;                    // [sum(2n+1)] never-moved members of each bucket
     // per-bucket LIFO stacks of moved vertices (geometric chunks, per-bucket directory)
     int32_t* bs_cnt; int32_t* bs_alloc;              // [sum(2n+1)] height, chunks allocated
@@ -345,47 +358,47 @@ RLAP_HD int32_t pool_take(int32_t* top, int32_t cnt) { int32_t r = *top; *top = 
 
 // Append one entry to column k; returns its slot or -1 on pool overflow.
 RLAP_HD int32_t col_append(const Arrays& A, int32_t k) {
-    int32_t a = A.app_cnt[k];
+    int32_t a = A.vr[k].app_cnt;
     int c = chunk_of(a);
     int cs = chunk_start(c);
     if (a == cs) {
         int32_t need = 1 + chunk_cap(c);
         int32_t base = pool_take(A.pool_top, need);
         if (base < 0 || base > A.slot_cap - need) return -1;
-        A.e_nbr[base] = A.app_chunk[k];
-        A.app_chunk[k] = base;
+        A.e[base].nbr = A.vr[k].app_chunk;
+        A.vr[k].app_chunk = base;
     }
-    A.app_cnt[k] = a + 1;
-    return A.app_chunk[k] + 1 + (a - cs);
+    A.vr[k].app_cnt = a + 1;
+    return A.vr[k].app_chunk + 1 + (a - cs);
 }
 
 // preconditioner.cc:248-271 on the array layout. Returns the live count.
 RLAP_HD int32_t serial_gather(const Arrays& A, int32_t v, const ColBuf& B, int32_t cap) {
     int32_t len = 0;
-    int32_t a = A.app_cnt[v];
+    int32_t a = A.vr[v].app_cnt;
     if (a > 0) {
-        int32_t base = A.app_chunk[v];
+        int32_t base = A.vr[v].app_chunk;
         int c = chunk_of(a - 1);
         int32_t idx = a - 1;
         while (idx >= 0) {
             int32_t cs = chunk_start(c);
             for (int32_t t = idx; t >= cs; --t) {
                 int32_t s = base + 1 + (t - cs);
-                double val = A.e_val[s];
+                double val = A.e[s].val;
                 if (val > 0) {
-                    if (len < cap) { B.a_slot[len] = s; B.a_nbr[len] = A.e_nbr[s]; B.a_val[len] = val; B.a_twin[len] = A.e_twin[s]; }
+                    if (len < cap) { B.a_slot[len] = s; B.a_nbr[len] = A.e[s].nbr; B.a_val[len] = val; B.a_twin[len] = A.e[s].twin; }
                     ++len;
                 }
             }
             idx = cs - 1;
-            base = A.e_nbr[base];
+            base = A.e[base].nbr;
             --c;
         }
     }
     for (int32_t s = A.colptr[v + 1] - 1; s >= A.colptr[v]; --s) {
-        double val = A.e_val[s];
+        double val = A.e[s].val;
         if (val > 0) {
-            if (len < cap) { B.a_slot[len] = s; B.a_nbr[len] = A.e_nbr[s]; B.a_val[len] = val; B.a_twin[len] = A.e_twin[s]; }
+            if (len < cap) { B.a_slot[len] = s; B.a_nbr[len] = A.e[s].nbr; B.a_val[len] = val; B.a_twin[len] = A.e[s].twin; }
             ++len;
         }
     }
@@ -430,7 +443,7 @@ RLAP_HD int pq_push(const Arrays& A, GraphDesc& G, int32_t v, int32_t lst) {
     int32_t id = G.push_cnt++;
     A.bs_v[s] = v; A.bs_id[s] = id;
     A.bs_cnt[b] = a + 1;
-    A.pqpos[v] = id;
+    A.vr[v].pqpos = id;
     if (lst < G.minlist) G.minlist = lst;
     return ST_OK;
 }
@@ -443,13 +456,13 @@ RLAP_HD int32_t pq_pop(const Arrays& A, GraphDesc& G) {
             int32_t s = bs_slot(A, b, cnt - 1);
             --cnt;
             int32_t v = A.bs_v[s];
-            if (A.pqpos[v] == A.bs_id[s]) { A.bs_cnt[b] = cnt; A.pqpos[v] = -2; return v; }
+            if (A.vr[v].pqpos == A.bs_id[s]) { A.bs_cnt[b] = cnt; A.vr[v].pqpos = -2; return v; }
         }
         A.bs_cnt[b] = 0;
         int32_t oc = A.ocur[b], oe = A.oend[b];
         while (oc < oe) {
             int32_t v = A.orig_order[oc++];
-            if (A.pqpos[v] == -1) { A.ocur[b] = oc; A.pqpos[v] = -2; return v; }
+            if (A.vr[v].pqpos == -1) { A.ocur[b] = oc; A.vr[v].pqpos = -2; return v; }
         }
         A.ocur[b] = oc;
         G.minlist += 1;
@@ -462,7 +475,7 @@ RLAP_HD int32_t pq_pop(const Arrays& A, GraphDesc& G) {
 RLAP_HD int pq_commit_serial(const Arrays& A, GraphDesc& G, const ColBuf& B, int32_t m) {
     int32_t cnt = 0;
     for (int32_t x = 0; x < m; ++x) {
-        A.key[B.b_nbr[x]] = B.t_key[x];
+        A.vr[B.b_nbr[x]].key = B.t_key[x];
         if (B.t_mv[x] >= 0) { B.rec[cnt].key = (double)B.t_mv[x]; B.rec[cnt].idx = x; B.rec[cnt].aux = 0; ++cnt; }
     }
     std_sort_emul<false>(B.rec, cnt);  // distinct keys
@@ -486,12 +499,12 @@ RLAP_HD int32_t serial_sort_merge(const Arrays& A, const GraphDesc& G, const Col
         int32_t s = B.rec[i].idx;
         if (m == 0 || B.a_nbr[s] != B.b_nbr[m - 1]) {
             B.b_slot[m] = B.a_slot[s]; B.b_nbr[m] = B.a_nbr[s]; B.b_val[m] = B.a_val[s]; B.b_twin[m] = B.a_twin[s];
-            if (elim && use_pq) { B.t_key[m] = A.key[B.a_nbr[s]]; B.t_mv[m] = -1; }
+            if (elim && use_pq) { B.t_key[m] = A.vr[B.a_nbr[s]].key; B.t_mv[m] = -1; }
             ++m;
         } else {
             B.b_val[m - 1] += B.a_val[s];
             if (elim) {
-                A.e_val[B.a_twin[s]] = 0;
+                A.e[B.a_twin[s]].val = 0;
                 if (use_pq) pq_op(B.t_key[m - 1], B.t_mv[m - 1], G.n, -1, i);
             }
         }
@@ -529,8 +542,8 @@ RLAP_HD int32_t upper_index(const double* cum, int32_t m, double r) {  // first 
 RLAP_HD int serial_rewire(const Arrays& A, int32_t s_r, int32_t nbr_j, int32_t k, double w) {
     int32_t s_n = col_append(A, k);
     if (s_n < 0) return ST_POOL_OVERFLOW;
-    A.e_nbr[s_r] = k; A.e_val[s_r] = w; A.e_twin[s_r] = s_n;
-    A.e_nbr[s_n] = nbr_j; A.e_val[s_n] = w; A.e_twin[s_n] = s_r;
+    A.e[s_r].nbr = k; A.e[s_r].val = w; A.e[s_r].twin = s_n;
+    A.e[s_n].nbr = nbr_j; A.e[s_n].val = w; A.e[s_n].twin = s_r;
     return ST_OK;
 }
 
@@ -553,7 +566,7 @@ RLAP_HD int serial_eliminate(const Arrays& A, GraphDesc& G, const ColBuf& B, int
             int32_t koff = upper_index(B.cum, m, r);
             int32_t k = B.a_nbr[koff];
             double wk = B.a_val[koff];
-            A.e_val[B.a_twin[koff]] = 0;
+            A.e[B.a_twin[koff]].val = 0;
             int32_t xk = B.t_of[koff];
             pq_op(B.t_key[xk], B.t_mv[xk], G.n, -1, len0);
             for (int32_t j = 0; j < m; ++j) {
@@ -591,7 +604,7 @@ RLAP_HD int serial_eliminate(const Arrays& A, GraphDesc& G, const ColBuf& B, int
         }
         if (m > 0) {
             if (use_pq && e1 + 1 < (int64_t)G.n) { int32_t xl = B.t_of[m - 1]; pq_op(B.t_key[xl], B.t_mv[xl], G.n, -1, len0 + m); }
-            A.e_val[B.a_twin[m - 1]] = 0;
+            A.e[B.a_twin[m - 1]].val = 0;
         }
     }
     if (use_pq) return pq_commit_serial(A, G, B, m);
@@ -721,13 +734,13 @@ template <class CT>
 RLAP_HD void cand_meta(const Arrays& A, int32_t v, CT& C) {
     C.v = v; C.flags = 0; C.m = 0; C.ndraw = 0; C.koff = 0; C.nkill = 0; C.nmv = 0; C.ndep = 0;
     int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
-    int32_t acnt = A.app_cnt[v];
-    int32_t base = A.app_chunk[v];              // read with the counts (not after them): one dependent round trip less
+    int32_t acnt = A.vr[v].app_cnt;
+    int32_t base = A.vr[v].app_chunk;              // read with the counts (not after them): one dependent round trip less
     C.cp1 = cp1; C.acnt = acnt; C.ext = (cp1 - cp0) + acnt;
     if (C.ext > CT::CAP) { C.flags = CF_BIG; C.ext = 0; return; }
     if (acnt > 0) {
         int ct = chunk_of(acnt - 1);            // <= 2 (CAP 32) / <= 3 (CAP 64) because acnt <= CAP
-        for (int c = ct; c >= 0; --c) { C.cb[c] = base; if (c > 0) base = A.e_nbr[base]; }
+        for (int c = ct; c >= 0; --c) { C.cb[c] = base; if (c > 0) base = A.e[base].nbr; }
     }
 }
 // traversal position e of the column (:248-271): appended entries newest first, then the CSR segment backwards
@@ -743,7 +756,7 @@ RLAP_HD int32_t cand_slot(const CT& C, int32_t e) {
 template <class CT>
 RLAP_HD void cand_load(const Arrays& A, CT& C, int32_t e) {
     int32_t s = cand_slot(C, e);
-    C.e[e].val = A.e_val[s]; C.e[e].nbr = A.e_nbr[s]; C.e[e].twin = A.e_twin[s]; C.e[e].aux = 0;
+    C.e[e].val = A.e[s].val; C.e[e].nbr = A.e[s].nbr; C.e[e].twin = A.e[s].twin; C.e[e].aux = 0;
 }
 // drop dead entries -> sort by id (:275) -> multi-edges go to the single-vertex path -> order by o_n (:295-307)
 template <class CT>

@@ -82,21 +82,19 @@ __global__ void k_collect(const int32_t* flags, const double* acc, const int32_t
                           const int32_t* pool_top, const int32_t* bs_pool_top, CallResults* out);
 __global__ void k_heads(const uint64_t* keys, int64_t E, int32_t* head);
 __global__ void k_fill_csr(const uint64_t* keys, const uint32_t* idx, const int32_t* head, const int32_t* pos, const double* w,
-                           int64_t E, int set_semantics, int32_t* e_nbr, double* e_val, int32_t* slot_col);
+                           int64_t E, int set_semantics, Slot* ent, int32_t* slot_col);
 __global__ void k_colptr(const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int32_t* colptr);
-__global__ void k_twin_sym(const int32_t* colptr, const int32_t* e_nbr, const double* e_val, const int32_t* slot_col, const int32_t* nnz_p,
-                           int32_t* e_twin, double* acc);
-__global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, int32_t* key, int32_t* pqpos, int32_t* app_cnt,
-                          int32_t* app_chunk, uint64_t* skey, uint32_t* sval);
-__global__ void k_bucket_bounds(const uint32_t* order, const int32_t* key, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
+__global__ void k_twin_sym(const int32_t* colptr, Slot* ent, const int32_t* slot_col, const int32_t* nnz_p, double* acc);
+__global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, VRec* vr, uint64_t* skey, uint32_t* sval);
+__global__ void k_bucket_bounds(const uint32_t* order, const VRec* vr, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
                                 int32_t* ocur, int32_t* oend, int32_t* origpos);
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
                             int32_t* batch_pos, const int32_t* flags, const double* acc);
-__global__ void k_sc_keys(const int32_t* key, const int32_t* pqpos, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,
+__global__ void k_sc_keys(const VRec* vr, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,
                           int32_t N, uint64_t* skey, uint32_t* sval);
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,
                                 uint32_t* order);
-__global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const int32_t* app_cnt, int32_t S, int32_t* ext);
+__global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const VRec* vr, int32_t S, int32_t* ext);
 constexpr unsigned NHUGE = 32;   // workgroups of k_sc_merge_huge
 struct ScLaunch { hipStream_t main; hipStream_t side[2]; hipEvent_t ev[3]; };   // side streams may be null: everything on `main`
 void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,

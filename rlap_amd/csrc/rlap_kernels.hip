@@ -241,7 +241,7 @@ __global__ void k_heads(const uint64_t* __restrict__ keys, int64_t E, int32_t* _
 
 __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const int32_t* __restrict__ head,
                            const int32_t* __restrict__ pos, const double* __restrict__ w, int64_t E, int set_semantics,
-                           int32_t* __restrict__ e_nbr, double* __restrict__ e_val, int32_t* __restrict__ slot_col) {
+                           Slot* __restrict__ ent, int32_t* __restrict__ slot_col) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E || !head[i]) return;
     uint64_t k = keys[i];
@@ -250,8 +250,8 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
     // duplicates summed in input order (setFromTriplets); unweighted symmetrised input is an edge SET (PyG coalesce): weight 1
     if (!set_semantics) for (int64_t q = i + 1; q < E && keys[q] == k; ++q) sum += w ? w[idx[q]] : 1.0;
     int32_t c = (int32_t)(k >> 32);
-    e_nbr[s] = (int32_t)(k & 0xFFFFFFFFull);
-    e_val[s] = sum;
+    Slot g; g.val = sum; g.nbr = (int32_t)(k & 0xFFFFFFFFull); g.twin = -1;
+    ent[s] = g;
     slot_col[s] = c;
 }
 
@@ -271,28 +271,28 @@ __global__ void k_colptr(const int32_t* __restrict__ slot_col, const int32_t* __
 // K2 + K3: twin index by binary search in the neighbour's (sorted) segment and
 // the isApprox(A^T) test: ||A-A^T||_F^2 <= 1e-24 ||A||_F^2 (Eigen default prec).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ colptr, const int32_t* __restrict__ e_nbr,
-                                                  const double* __restrict__ e_val, const int32_t* __restrict__ slot_col,
-                                                  const int32_t* __restrict__ nnz_p, int32_t* __restrict__ e_twin, double* __restrict__ acc) {
+__global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ colptr, Slot* __restrict__ ent,
+                                                  const int32_t* __restrict__ slot_col,
+                                                  const int32_t* __restrict__ nnz_p, double* __restrict__ acc) {
     const int32_t nnz = *nnz_p;
     double d2 = 0, n2 = 0;
     bool asym = false;
     for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += gridDim.x * blockDim.x) {
-        int32_t c = slot_col[p], r = e_nbr[p];
-        double v = e_val[p];
+        int32_t c = slot_col[p], r = ent[p].nbr;
+        double v = ent[p].val;
         n2 += v * v;
         int32_t lo = colptr[r], hi = colptr[r + 1];
         const int32_t end = hi;
         while (lo < hi) {
             int32_t mid = (lo + hi) >> 1;
-            if (e_nbr[mid] < c) lo = mid + 1; else hi = mid;
+            if (ent[mid].nbr < c) lo = mid + 1; else hi = mid;
         }
-        if (lo < end && e_nbr[lo] == c) {
-            e_twin[p] = lo;
-            double d = v - e_val[lo];
+        if (lo < end && ent[lo].nbr == c) {
+            ent[p].twin = lo;
+            double d = v - ent[lo].val;
             d2 += d * d;
         } else {
-            e_twin[p] = -1;
+            ent[p].twin = -1;
             d2 += 2 * v * v;
             asym = true;
         }
@@ -315,32 +315,29 @@ __global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ co
 // descending id (= LIFO order after ascending insertion, :137-157).
 // ---------------------------------------------------------------------------
 __global__ void k_pq_init(const int32_t* __restrict__ colptr, const int32_t* __restrict__ vgraph, int32_t N,
-                          int32_t* __restrict__ key, int32_t* __restrict__ pqpos, int32_t* __restrict__ app_cnt,
-                          int32_t* __restrict__ app_chunk, uint64_t* __restrict__ skey, uint32_t* __restrict__ sval) {
+                          VRec* __restrict__ vr, uint64_t* __restrict__ skey, uint32_t* __restrict__ sval) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     int32_t v = N - 1 - i;  // descending id; the (stable) sort keeps this order inside a bucket
     int32_t d = colptr[v + 1] - colptr[v];
-    key[v] = d;
-    pqpos[v] = -1;
-    app_cnt[v] = 0;
-    app_chunk[v] = -1;
+    VRec r; r.key = d; r.pqpos = -1; r.app_cnt = 0; r.app_chunk = -1;
+    vr[v] = r;
     skey[i] = ((uint64_t)(uint32_t)vgraph[v] << 32) | (uint32_t)d;
     sval[i] = (uint32_t)v;
 }
 
-__global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const int32_t* __restrict__ key, const int32_t* __restrict__ vgraph,
+__global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const VRec* __restrict__ vr, const int32_t* __restrict__ vgraph,
                                 const GraphDesc* __restrict__ gd, int32_t N, int32_t* __restrict__ ocur, int32_t* __restrict__ oend,
                                 int32_t* __restrict__ origpos) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     int32_t v = (int32_t)order[i];
     origpos[v] = i;
-    int32_t g = vgraph[v], d = key[v];
+    int32_t g = vgraph[v], d = vr[v].key;
     int32_t b = gd[g].bucket_base + d;
     bool first = true, last = true;
-    if (i > 0) { int32_t u = (int32_t)order[i - 1]; first = !(vgraph[u] == g && key[u] == d); }
-    if (i < N - 1) { int32_t u = (int32_t)order[i + 1]; last = !(vgraph[u] == g && key[u] == d); }
+    if (i > 0) { int32_t u = (int32_t)order[i - 1]; first = !(vgraph[u] == g && vr[u].key == d); }
+    if (i < N - 1) { int32_t u = (int32_t)order[i + 1]; last = !(vgraph[u] == g && vr[u].key == d); }
     if (first) ocur[b] = i;
     if (last) oend[b] = i + 1;
 }
@@ -874,7 +871,7 @@ __device__ __forceinline__ int32_t alloc_in_column(const Arrays& A, int32_t& a, 
         int32_t need = 1 + chunk_cap(c);
         int32_t base = atomicAdd(A.pool_top, need);
         if (base < 0 || base > A.slot_cap - need) { *status = ST_POOL_OVERFLOW; return 0; }
-        A.e_nbr[base] = chunk;
+        A.e[base].nbr = chunk;
         chunk = base;
     }
     int32_t s = chunk + 1 + (a - cs);
@@ -906,21 +903,21 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
                 bool valid = t >= cs;
                 int32_t s = base + 1 + (t - cs);
                 double val = 0; int32_t nb = 0, tw = 0;
-                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; tw = A.e_twin[s]; }
+                if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; tw = g.twin; }
                 bool live = valid && val > 0;
                 uint64_t mask = __ballot(live);
                 int pos = len0 + popc64(mask & lt);
                 if (live) { L.a_slot[pos] = s; L.a_nbr[pos] = nb; L.a_val[pos] = val; L.a_twin[pos] = tw; }
                 len0 += popc64(mask);
             }
-            int32_t prev = A.e_nbr[base];
+            int32_t prev = A.e[base].nbr;
             idx = cs - 1; base = prev; --c;
         }
         for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
             int32_t s = s0 - lane;
             bool valid = s >= cp0;
             double val = 0; int32_t nb = 0, tw = 0;
-            if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; tw = A.e_twin[s]; }
+            if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; tw = g.twin; }
             bool live = valid && val > 0;
             uint64_t mask = __ballot(live);
             int pos = len0 + popc64(mask & lt);
@@ -957,7 +954,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             L.b_slot[x] = L.a_slot[src]; L.b_nbr[x] = nb; L.b_twin[x] = L.a_twin[src]; L.b_val[x] = val;
             L.b_pos[x] = lane; L.b_dup[x] = d;
         } else if (act) {
-            A.e_val[L.a_twin[src]] = 0;  // duplicate's twin dies (:289)
+            A.e[L.a_twin[src]].val = 0;  // duplicate's twin dies (:289)
         }
     } else {
         for (int p0 = 0; p0 < len0; p0 += 64) {
@@ -976,7 +973,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
                 L.b_slot[x] = L.a_slot[src]; L.b_nbr[x] = nb; L.b_twin[x] = L.a_twin[src]; L.b_val[x] = val;
                 L.b_pos[x] = p; L.b_dup[x] = d;
             } else if (act) {
-                A.e_val[L.a_twin[src]] = 0;  // duplicate's twin dies (:289)
+                A.e[L.a_twin[src]].val = 0;  // duplicate's twin dies (:289)
             }
             m += popc64(mask);
         }
@@ -987,9 +984,9 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     // ---- neighbour metadata (PQ key, append cursor): issued now, used after ordering ----
     for (int x = lane; x < m; x += 64) {
         int32_t nb = L.b_nbr[x];
-        L.t_cnt[x] = A.app_cnt[nb];
-        L.t_chunk[x] = A.app_chunk[nb];
-        L.t_key[x] = use_pq ? A.key[nb] : 0;
+        L.t_cnt[x] = A.vr[nb].app_cnt;
+        L.t_chunk[x] = A.vr[nb].app_chunk;
+        L.t_key[x] = use_pq ? A.vr[nb].key : 0;
     }
 
     // ---- order neighbours by o_n (:295-307) ----
@@ -1109,7 +1106,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             WAVE_SYNC();
         }
         for (int x = lane; x < m; x += 64) {
-            if (L.t_cnt[x] != L.t_list[x]) { A.app_cnt[L.b_nbr[x]] = L.t_cnt[x]; A.app_chunk[L.b_nbr[x]] = L.t_chunk[x]; }
+            if (L.t_cnt[x] != L.t_list[x]) { A.vr[L.b_nbr[x]].app_cnt = L.t_cnt[x]; A.vr[L.b_nbr[x]].app_chunk = L.t_chunk[x]; }
         }
     } else
     for (int x = lane; x < m; x += 64) {
@@ -1138,9 +1135,9 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             }
             if (use_pq && x == L.t_of[m - 1] && e1 + 1 < (int64_t)G.n) pq_op(key, mv, G.n, -1, len0 + m);
         }
-        if (a != a_before) { A.app_cnt[L.b_nbr[x]] = a; A.app_chunk[L.b_nbr[x]] = chunk; }
+        if (a != a_before) { A.vr[L.b_nbr[x]].app_cnt = a; A.vr[L.b_nbr[x]].app_chunk = chunk; }
         if (use_pq) {
-            if (key != L.t_key[x]) A.key[L.b_nbr[x]] = key;
+            if (key != L.t_key[x]) A.vr[L.b_nbr[x]].key = key;
             L.t_key[x] = key;
             L.t_mv[x] = mv;
             L.t_list[x] = mv >= 0 ? pq_list_of(key, G.n) : -1;
@@ -1157,18 +1154,18 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             double w = L.a_val[j];
             double nw = (wk_c * w) / (wk_c + w);
             int32_t k = L.a_nbr[koff_c], s_r = L.a_twin[j], s_n = L.pslot[j];
-            A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
-            A.e_nbr[s_n] = L.a_nbr[j]; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+            A.e[s_r].nbr = k; A.e[s_r].val = nw; A.e[s_r].twin = s_n;
+            A.e[s_n].nbr = L.a_nbr[j]; A.e[s_n].val = nw; A.e[s_n].twin = s_r;
         }
-        if (lane == 0 && m >= 1) A.e_val[L.a_twin[koff_c]] = 0;
+        if (lane == 0 && m >= 1) A.e[L.a_twin[koff_c]].val = 0;
     } else {
         for (int j = lane; j < m - 1; j += 64) {
             double nw = newv[j];
             int32_t k = L.a_nbr[L.ksel[j]], s_r = L.a_twin[j], s_n = L.pslot[j];
-            A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
-            A.e_nbr[s_n] = L.a_nbr[j]; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+            A.e[s_r].nbr = k; A.e[s_r].val = nw; A.e[s_r].twin = s_n;
+            A.e[s_n].nbr = L.a_nbr[j]; A.e[s_n].val = nw; A.e[s_n].twin = s_r;
         }
-        if (lane == 0 && m >= 1) A.e_val[L.a_twin[m - 1]] = 0;  // :429-430
+        if (lane == 0 && m >= 1) A.e[L.a_twin[m - 1]].val = 0;  // :429-430
     }
 
     WSTAMP(7);
@@ -1247,21 +1244,21 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
                 bool valid = t >= cs;
                 int32_t s = base + 1 + (t - cs);
                 double val = 0; int32_t nb = 0, tw = 0;
-                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; tw = A.e_twin[s]; }
+                if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; tw = g.twin; }
                 bool live = valid && val > 0;
                 uint64_t mask = __ballot(live);
                 int pos = len0 + popc64(mask & lt);
                 if (live && pos < cap) { B.a_slot[pos] = s; B.a_nbr[pos] = nb; B.a_val[pos] = val; B.a_twin[pos] = tw; }
                 len0 += popc64(mask);
             }
-            int32_t prev = A.e_nbr[base];
+            int32_t prev = A.e[base].nbr;
             idx = cs - 1; base = prev; --c;
         }
         for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
             int32_t s = s0 - lane;
             bool valid = s >= cp0;
             double val = 0; int32_t nb = 0, tw = 0;
-            if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; tw = A.e_twin[s]; }
+            if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; tw = g.twin; }
             bool live = valid && val > 0;
             uint64_t mask = __ballot(live);
             int pos = len0 + popc64(mask & lt);
@@ -1295,7 +1292,7 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
             for (int q = p + 1; q < len0 && B.a_nbr[L.rec[q].idx] == nb; ++q) val += B.a_val[L.rec[q].idx];
             B.b_slot[x] = B.a_slot[s]; B.b_nbr[x] = nb; B.b_twin[x] = B.a_twin[s]; B.b_val[x] = val;
         } else if (act) {
-            A.e_val[B.a_twin[s]] = 0;   // duplicate's twin dies (:655)
+            A.e[B.a_twin[s]].val = 0;   // duplicate's twin dies (:655)
         }
         m += popc64(mask);
     }
@@ -1368,25 +1365,25 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
             mymask &= mybit ? bb : ~bb;
         }
         if (act && lane == __builtin_ctzll(mymask)) {
-            int32_t a = ld_agent(&A.app_cnt[k]), chunk = ld_agent(&A.app_chunk[k]);
+            int32_t a = ld_agent(&A.vr[k].app_cnt), chunk = ld_agent(&A.vr[k].app_chunk);
             uint64_t mm = mymask;
             while (mm) { const int l = __builtin_ctzll(mm); mm &= mm - 1; L.tmp[l] = alloc_in_column(A, a, chunk, &status); }
-            A.app_cnt[k] = a; A.app_chunk[k] = chunk;
+            A.vr[k].app_cnt = a; A.vr[k].app_chunk = chunk;
         }
         __threadfence();
         WAVE_SYNC();
         if (act && status == 0) {
             const int32_t s_r = B.a_twin[j], s_n = L.tmp[lane];
             const double nw = newv[j];
-            A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
-            A.e_nbr[s_n] = B.a_nbr[j]; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+            A.e[s_r].nbr = k; A.e[s_r].val = nw; A.e[s_r].twin = s_n;
+            A.e[s_n].nbr = B.a_nbr[j]; A.e[s_n].val = nw; A.e[s_n].twin = s_r;
         }
         WAVE_SYNC();
         if (__ballot(status != 0) != 0ull) break;
     }
     if (__ballot(status != 0) != 0ull) { if (lane == 0) G.status = ST_POOL_OVERFLOW; WAVE_SYNC(); return true; }
     if (lane == 0) {
-        if (m >= 1) A.e_val[B.a_twin[m - 1]] = 0;   // :791-792
+        if (m >= 1) A.e[B.a_twin[m - 1]].val = 0;   // :791-792
         G.n_draws = draws0 + ndraw;
     }
     WAVE_SYNC();
@@ -1455,8 +1452,10 @@ __device__ __forceinline__ int block_rank(bool flag, int* scratch, int* total) {
 
 // rewire stores of one push (preconditioner.cc:404-414)
 __device__ __forceinline__ void rewire_store(const Arrays& A, int32_t s_r, int32_t s_n, int32_t nbr_j, int32_t k, double nw) {
-    A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
-    A.e_nbr[s_n] = nbr_j; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+    Slot a; a.val = nw; a.nbr = k; a.twin = s_n;
+    Slot b; b.val = nw; b.nbr = nbr_j; b.twin = s_r;
+    A.e[s_r] = a;     // one 16-byte store per slot
+    A.e[s_n] = b;
 }
 
 // all pushes of candidate C into the column of its target at position j, in position order
@@ -1660,7 +1659,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 Arrays A2 = A;
                 ElimScratch S2 = S;
                 int32_t cp0 = A2.colptr[v0], cp1 = A2.colptr[v0 + 1];
-                int32_t acnt = A2.app_cnt[v0], abase = A2.app_chunk[v0];
+                int32_t acnt = A2.vr[v0].app_cnt, abase = A2.vr[v0].app_chunk;
                 if ((cp1 - cp0) + acnt > ECAP) {
                     ColBuf Bf = S2.colbuf(G.scr_base);
                     const bool handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
@@ -1697,11 +1696,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     if (a >= 0) {
                         int32_t sl = bs_slot(A, b, a);
                         v_s = A.bs_v[sl];
-                        vs = (A.pqpos[v_s] == A.bs_id[sl]);
+                        vs = (A.vr[v_s].pqpos == A.bs_id[sl]);
                     }
                     const bool last_stack = top <= NT;
                     const int32_t oc = oc0 + tid;
-                    if (last_stack && oc < oe) { v_o = A.orig_order[oc]; vo = (A.pqpos[v_o] == -1); }
+                    if (last_stack && oc < oe) { v_o = A.orig_order[oc]; vo = (A.vr[v_o].pqpos == -1); }
                     int tot;
                     const int r = block_excl_scan<NWAVE>((vs ? 1 : 0) | (vo ? (1 << 16) : 0), L.scan, &tot);
                     const int rs = r & 0xFFFF, ro = r >> 16, ts = tot & 0xFFFF, to = tot >> 16;
@@ -1757,7 +1756,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 lv[k] = 0; ln[k] = 0; lt[k] = 0;
                 if (la[k]) {
                     int32_t sl = cand_slot(L.cand[i], e);
-                    lv[k] = A.e_val[sl]; ln[k] = A.e_nbr[sl]; lt[k] = A.e_twin[sl];
+                    const Slot g = A.e[sl]; lv[k] = g.val; ln[k] = g.nbr; lt[k] = g.twin;
                 }
             }
             // dependence: is a live neighbour an earlier candidate of this round?  Looked up now (only the ids are needed), so
@@ -2175,7 +2174,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 if (i >= Pmax) continue;
                 if (j < L.cand[i].m) {
                     const int32_t x = L.cand[i].e[j].nbr;
-                    if (use_pq) key0k[k] = A.key[x];
+                    if (use_pq) key0k[k] = A.vr[x].key;
                     uint32_t hh = ((uint32_t)x * 2654435761u) >> (32 - HBITS);
                     while (true) {   // linear probing; at most SLOTS distinct keys in SLOTS places
                         const int32_t cur = hkeys[hh];
@@ -2238,7 +2237,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             for (int32_t q = tid; q < ncont; q += NT) {
                 if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;   // group head only
                 int32_t x = csorted[q].x;
-                int32_t key = use_pq ? A.key[x] : 1;
+                int32_t key = use_pq ? A.vr[x].key : 1;
                 for (int32_t r = q; r < ncont && csorted[r].x == x; ++r) {
                     Cand& C = L.cand[csorted[r].i];
                     const bool allow_last = (done + csorted[r].i + 1) + 1 < (int64_t)n;
@@ -2279,7 +2278,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             if (tid < nc) batch_pos[L.cand[tid].v] = -1;
             if (tid == 0 && use_pq) {
                 if (src0 >= 0) A.bs_cnt[b] = src0; else { A.bs_cnt[b] = 0; A.ocur[b] = (~src0) + 1; }
-                A.pqpos[v0] = -2;
+                A.vr[v0].pqpos = -2;
             }
             __syncthreads();
             if (tid < 64) {
@@ -2289,7 +2288,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 Arrays A2 = A;
                 ElimScratch S2 = S;
                 int32_t cp0 = A2.colptr[v0], cp1 = A2.colptr[v0 + 1];
-                int32_t acnt = A2.app_cnt[v0], abase = A2.app_chunk[v0];
+                int32_t acnt = A2.vr[v0].app_cnt, abase = A2.vr[v0].app_chunk;
                 if ((cp1 - cp0) + acnt > ECAP) {
                     bool handled = false;
                     if (OV == OV_RANDOM) {
@@ -2317,13 +2316,13 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         int32_t status = 0;
         if (tid < P) {
             Cand& C = L.cand[tid];
-            if (use_pq) A.pqpos[C.v] = -2;
+            if (use_pq) A.vr[C.v].pqpos = -2;
             // the edge to the last neighbour (or to the coarsening target) dies (:429-430 | :880-881)
             if (C.m >= 1) {
                 const int32_t tw = C.e[A.o_v == OV_COARSEN ? C.koff : C.m - 1].twin;
-                if (!PATCH || tw >= 0) A.e_val[tw] = 0;   // (a patched entry's twin is appended in this very round: second pass of the rewire stores)
+                if (!PATCH || tw >= 0) A.e[tw].val = 0;   // (a patched entry's twin is appended in this very round: second pass of the rewire stores)
             }
-            if (MERGE) for (int32_t q = 0; q < C.nkill; ++q) A.e_val[C.e[C.m + q].twin] = 0;   // merged multi-edges (:289)
+            if (MERGE) for (int32_t q = 0; q < C.nkill; ++q) A.e[C.e[C.m + q].twin].val = 0;   // merged multi-edges (:289)
         }
         // append cursors of the targets shared by several candidates: loaded now (one group head per thread), used
         // after the pool bump below
@@ -2333,7 +2332,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         if (tid < ncont_c) {
             const CRec me = L.csorted[tid];
             chead = (tid == 0 || L.csorted[tid - 1].x != me.x) && me.i < P;
-            if (chead) { ca0 = A.app_cnt[me.x]; cchunk0 = A.app_chunk[me.x]; }
+            if (chead) { ca0 = A.vr[me.x].app_cnt; cchunk0 = A.vr[me.x].app_chunk; }
             // which positions of candidate me.i push into this target: found here by every record's own thread, so that
             // the group walk below only steps through the set bits (the unsorted record list is free: used as scratch)
             uint64_t pm = 0ull;
@@ -2359,7 +2358,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     xk[k] = L.cand[i].e[j].nbr;
                     actk[k] = !(Rk[k].flags & TF_CONTENDED);
                 }
-                if (actk[k] && Rk[k].c > 0) { a0k[k] = A.app_cnt[xk[k]]; chk[k] = A.app_chunk[xk[k]]; }
+                if (actk[k] && Rk[k].c > 0) { a0k[k] = A.vr[xk[k]].app_cnt; chk[k] = A.vr[xk[k]].app_chunk; }
             }
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
@@ -2407,11 +2406,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                         if (co ? (p == C.koff) : (C.ksel[p] != j)) continue;
                         int c = chunk_of(a);
                         int32_t cs = chunk_start(c);
-                        if (a == cs) { A.e_nbr[cursor] = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
+                        if (a == cs) { A.e[cursor].nbr = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
                         L.pslot[i * BCAP + p] = chunk + 1 + (a - cs);
                         ++a;
                     }
-                    A.app_cnt[xk[k]] = a; A.app_chunk[xk[k]] = chunk;
+                    A.vr[xk[k]].app_cnt = a; A.vr[xk[k]].app_chunk = chunk;
                 }
                 const bool mvd = use_pq && actk[k] && Rk[k].mv >= 0;
                 const uint64_t mvmask = __ballot(mvd);
@@ -2421,7 +2420,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     qbase = __shfl(qbase, __builtin_ctzll(mvmask));
                 }
                 if (mvd) {
-                    A.key[xk[k]] = Rk[k].key_after;
+                    A.vr[xk[k]].key = Rk[k].key_after;
                     atomicOr(&L.cmask[i], 1ull << (Rk[k].mv - L.cand[i].m));
                     int32_t q = qbase + __popcll(mvmask & lanemask_lt(lane));
                     if (q < MCAP) {
@@ -2450,9 +2449,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     key_final = R.key_after;
                     if (R.mv >= 0) mvseq = (csorted[r].i << 8) | R.mv;
                 }
-                if (a != a_before) { A.app_cnt[x] = a; A.app_chunk[x] = chunk; }
+                if (a != a_before) { A.vr[x].app_cnt = a; A.vr[x].app_chunk = chunk; }
                 if (use_pq) {
-                    A.key[x] = key_final;
+                    A.vr[x].key = key_final;
                     if (mvseq >= 0) {
                         atomicOr(&L.cmask[mvseq >> 8], 1ull << ((mvseq & 0xFF) - L.cand[mvseq >> 8].m));
                         int32_t qq = atomicAdd(&s_nmoves, 1);
@@ -2491,7 +2490,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     if (pp < C.m && C.e[pp].twin < 0) {
                         const int32_t s_r = L.pslot[~C.e[pp].twin];
                         if (pp < C.m - 1) rewire_store(A, s_r, L.pslot[i * BCAP + pp], C.e[pp].nbr, C.e[(int32_t)C.ksel[pp]].nbr, C.e[pp].val);
-                        else A.e_val[s_r] = 0;
+                        else A.e[s_r].val = 0;
                     }
                 }
             }
@@ -2729,7 +2728,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             if (mine) {
                 int32_t sl = A.bs_dir[(int64_t)bk * BDIR + c_my] + (a_my - bs_chunk_start(c_my));
                 A.bs_v[sl] = x_my; A.bs_id[sl] = id0 + pos_my;
-                A.pqpos[x_my] = id0 + pos_my;
+                A.vr[x_my].pqpos = id0 + pos_my;
                 if (tail_my) {   // last move of its bucket group: the stack's new height (and chunk count)
                     A.bs_cnt[bk] = a_my + 1;
                     if (c_my + 1 > al_my) A.bs_alloc[bk] = c_my + 1;
@@ -2785,16 +2784,17 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t 
 // sc_merge (pass A): per vertex gather -> sort -> merge -> order -> staging;
 // sc_compact (pass B): prefix-sum compaction of the staged rows into (m,3) f64.
 // ---------------------------------------------------------------------------
-__global__ void k_sc_keys(const int32_t* __restrict__ key, const int32_t* __restrict__ pqpos, const int32_t* __restrict__ origpos,
+__global__ void k_sc_keys(const VRec* __restrict__ vr, const int32_t* __restrict__ origpos,
                           const int32_t* __restrict__ vgraph, const GraphDesc* __restrict__ gd, int32_t N,
                           uint64_t* __restrict__ skey, uint32_t* __restrict__ sval) {
     int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= N) return;
-    int32_t pp = pqpos[v];
+    const VRec me = vr[v];
+    int32_t pp = me.pqpos;
     uint64_t k = ~0ull;
     if (pp != -2) {
         const GraphDesc& D = gd[vgraph[v]];
-        uint32_t b = (uint32_t)(D.bucket_base + pq_list_of(key[v], D.n));
+        uint32_t b = (uint32_t)(D.bucket_base + pq_list_of(me.key, D.n));
         uint32_t ord = pp >= 0 ? (0x7FFFFFFFu - (uint32_t)pp) : (0x80000000u + (uint32_t)origpos[v]);
         k = ((uint64_t)b << 32) | ord;
     }
@@ -2815,12 +2815,12 @@ __global__ void k_sc_perm_order(const int64_t* __restrict__ perm, const int32_t*
     if (q >= D.n_elim) order[surv_base[g] + (q - D.n_elim)] = (uint32_t)(D.vbase + (int32_t)pl);
 }
 
-__global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __restrict__ colptr, const int32_t* __restrict__ app_cnt,
+__global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __restrict__ colptr, const VRec* __restrict__ vr,
                          int32_t S, int32_t* __restrict__ ext) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
     int32_t v = (int32_t)order[i];
-    ext[i] = (colptr[v + 1] - colptr[v]) + app_cnt[v];
+    ext[i] = (colptr[v + 1] - colptr[v]) + vr[v].app_cnt;
 }
 
 // test hook: one wave sorts one array of doubles, returns the permutation (tests/test_gpu_parity.py)
@@ -2956,10 +2956,10 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
             continue;
         }
         const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
-        const int32_t acnt = A.app_cnt[v];
+        const int32_t acnt = A.vr[v].app_cnt;
         int len0 = 0;
         {
-            int32_t idx = acnt - 1, base = A.app_chunk[v];
+            int32_t idx = acnt - 1, base = A.vr[v].app_chunk;
             int c = idx >= 0 ? chunk_of(idx) : 0;
             while (idx >= 0) {
                 int32_t cs = chunk_start(c);
@@ -2968,21 +2968,21 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
                     bool valid = t >= cs;
                     int32_t s = base + 1 + (t - cs);
                     double val = 0; int32_t nb = 0;
-                    if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                    if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; }
                     bool live = valid && val > 0;
                     uint64_t mask = __ballot(live);
                     int pos = len0 + popc64(mask & lt);
                     if (live) { L.a_nbr[pos] = nb; L.a_val[pos] = val; }
                     len0 += popc64(mask);
                 }
-                int32_t prev = A.e_nbr[base];
+                int32_t prev = A.e[base].nbr;
                 idx = cs - 1; base = prev; --c;
             }
             for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
                 int32_t s = s0 - lane;
                 bool valid = s >= cp0;
                 double val = 0; int32_t nb = 0;
-                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; }
                 bool live = valid && val > 0;
                 uint64_t mask = __ballot(live);
                 int pos = len0 + popc64(mask & lt);
@@ -3140,13 +3140,13 @@ __global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const GraphDesc*
             toff = tmp_off[i];
             const int32_t cp0 = A.colptr[v];
             cp1 = A.colptr[v + 1];
-            acnt = A.app_cnt[v];
+            acnt = A.vr[v].app_cnt;
             ext = (cp1 - cp0) + acnt;
             if (acnt > 0) {   // bases of the (at most three) appended chunks
                 const int ct = chunk_of(acnt - 1);
-                int32_t base = A.app_chunk[v];
-                if (ct == 2) { cb2 = base; base = A.e_nbr[base]; }
-                if (ct >= 1) { cb1 = base; base = A.e_nbr[base]; }
+                int32_t base = A.vr[v].app_chunk;
+                if (ct == 2) { cb2 = base; base = A.e[base].nbr; }
+                if (ct >= 1) { cb1 = base; base = A.e[base].nbr; }
                 cb0 = base;
             }
         }
@@ -3156,7 +3156,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const GraphDesc*
             int32_t sl;
             if (gl < acnt) { const int32_t a = acnt - 1 - gl; const int c = chunk_of(a); sl = (c == 0 ? cb0 : c == 1 ? cb1 : cb2) + 1 + (a - chunk_start(c)); }
             else sl = cp1 - 1 - (gl - acnt);
-            val = A.e_val[sl]; nb = A.e_nbr[sl];
+            val = A.e[sl].val; nb = A.e[sl].nbr;
         }
         const bool live = gl < ext && val > 0;
         const uint64_t lm = __ballot(live) & gmask;
@@ -3304,7 +3304,7 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
         const int32_t v = (int32_t)order[i];
         const int64_t toff = tmp_off[i];
         const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
-        const int32_t acnt = A.app_cnt[v];
+        const int32_t acnt = A.vr[v].app_cnt;
         Rec2* R = lds_R;
         if (HUGE) {
             if (lane == 0) {
@@ -3317,7 +3317,7 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
         }
         int len0 = 0;
         {
-            int32_t idx = acnt - 1, base = A.app_chunk[v];
+            int32_t idx = acnt - 1, base = A.vr[v].app_chunk;
             int c = idx >= 0 ? chunk_of(idx) : 0;
             while (idx >= 0) {
                 int32_t cs = chunk_start(c);
@@ -3326,21 +3326,21 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
                     bool valid = t >= cs;
                     int32_t s = base + 1 + (t - cs);
                     double val = 0; int32_t nb = 0;
-                    if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                    if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; }
                     bool live = valid && val > 0;
                     uint64_t mask = __ballot(live);
                     int pos = len0 + popc64(mask & lt);
                     if (live) { R[pos].a = (double)nb; R[pos].b = val; }
                     len0 += popc64(mask);
                 }
-                int32_t prev = A.e_nbr[base];
+                int32_t prev = A.e[base].nbr;
                 idx = cs - 1; base = prev; --c;
             }
             for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
                 int32_t s = s0 - lane;
                 bool valid = s >= cp0;
                 double val = 0; int32_t nb = 0;
-                if (valid) { val = A.e_val[s]; nb = A.e_nbr[s]; }
+                if (valid) { const Slot g = A.e[s]; val = g.val; nb = g.nbr; }
                 bool live = valid && val > 0;
                 uint64_t mask = __ballot(live);
                 int pos = len0 + popc64(mask & lt);

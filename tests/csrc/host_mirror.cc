@@ -19,8 +19,10 @@ namespace {
 struct Setup {
     int64_t n, t;
     int32_t nnz, cap;
-    std::vector<int32_t> colptr, e_nbr, e_twin, app_cnt, app_chunk, key, pqpos, ocur, oend, orig, bs_cnt, bs_alloc, bs_dir, bs_v, bs_id;
-    std::vector<double> e_val, rng;
+    std::vector<int32_t> colptr, ocur, oend, orig, bs_cnt, bs_alloc, bs_dir, bs_v, bs_id;
+    std::vector<Slot> ent;
+    std::vector<VRec> vrec;
+    std::vector<double> rng;
     std::vector<int64_t> perm_l;
     int32_t pool_top, bs_pool_top;
     Arrays A;
@@ -38,24 +40,25 @@ struct Setup {
         for (int64_t c = 0; c < n; ++c) colptr[c + 1] += colptr[c];
         nnz = colptr[n];
         int32_t slot_cap = nnz + pool_slots;
-        e_nbr.assign(slot_cap, 0); e_twin.assign(slot_cap, -1); e_val.assign(slot_cap, 0.0);
+        ent.assign(slot_cap, Slot{0.0, 0, -1});
         {
             std::vector<std::pair<int64_t, int64_t>> keyed;
             keyed.reserve(E);
             for (int64_t p = 0; p < E; ++p) if (w[p] != 0) keyed.push_back({col[p] * n + row[p], p});
             std::sort(keyed.begin(), keyed.end());
-            for (int32_t s = 0; s < nnz; ++s) { e_nbr[s] = (int32_t)row[keyed[s].second]; e_val[s] = w[keyed[s].second]; }
+            for (int32_t s = 0; s < nnz; ++s) { ent[s].nbr = (int32_t)row[keyed[s].second]; ent[s].val = w[keyed[s].second]; }
             std::vector<int32_t> cur(colptr.begin(), colptr.end() - 1);
             for (int64_t c = 0; c < n; ++c)
-                for (int32_t s = colptr[c]; s < colptr[c + 1]; ++s) e_twin[s] = cur[e_nbr[s]]++;
+                for (int32_t s = colptr[c]; s < colptr[c + 1]; ++s) ent[s].twin = cur[ent[s].nbr]++;
         }
-        app_cnt.assign(n, 0); app_chunk.assign(n, -1); key.assign(n, 0); pqpos.assign(n, -1);
+        vrec.assign(n, VRec{0, -1, 0, -1});
+        std::vector<int32_t> key((size_t)n, 0);
         ocur.assign(2 * n + 1, 0); oend.assign(2 * n + 1, 0); orig.assign(n, 0);
         bs_cnt.assign(2 * n + 1, 0); bs_alloc.assign(2 * n + 1, 0); bs_dir.assign((size_t)(2 * n + 1) * BDIR, -1);
         int32_t bs_pool_cap = 4 * (int32_t)E + BCH0 * (int32_t)(2 * n + 1) + 64;
         bs_pool_top = 0;
         bs_v.assign(bs_pool_cap, 0); bs_id.assign(bs_pool_cap, 0);
-        for (int64_t v = 0; v < n; ++v) { key[v] = colptr[v + 1] - colptr[v]; orig[v] = (int32_t)v; }
+        for (int64_t v = 0; v < n; ++v) { key[v] = colptr[v + 1] - colptr[v]; vrec[v].key = key[v]; orig[v] = (int32_t)v; }
         std::sort(orig.begin(), orig.end(), [&](int32_t a, int32_t b) { return key[a] != key[b] ? key[a] < key[b] : a > b; });
         for (int32_t i = 0; i < n;) {
             int32_t j = i;
@@ -77,9 +80,9 @@ struct Setup {
         perm_l.assign(n, 0);
         if (perm) for (int64_t i = 0; i < n; ++i) perm_l[i] = perm[i];
         pool_top = nnz;
-        A.colptr = colptr.data(); A.e_nbr = e_nbr.data(); A.e_val = e_val.data(); A.e_twin = e_twin.data();
-        A.slot_cap = slot_cap; A.pool_top = &pool_top; A.app_cnt = app_cnt.data(); A.app_chunk = app_chunk.data();
-        A.key = key.data(); A.pqpos = pqpos.data(); A.ocur = ocur.data(); A.oend = oend.data();
+        A.colptr = colptr.data(); A.e = ent.data();
+        A.slot_cap = slot_cap; A.pool_top = &pool_top; A.vr = vrec.data();
+        A.ocur = ocur.data(); A.oend = oend.data();
         A.orig_order = orig.data();
         A.bs_cnt = bs_cnt.data(); A.bs_alloc = bs_alloc.data(); A.bs_dir = bs_dir.data(); A.bs_v = bs_v.data(); A.bs_id = bs_id.data();
         A.bs_pool_top = &bs_pool_top; A.bs_pool_cap = bs_pool_cap;
@@ -157,12 +160,12 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
                 for (int32_t a = cnt - 1; a >= 0 && nc < Bcur; --a) {
                     int32_t s = bs_slot(A, b, a);
                     int32_t v = A.bs_v[s];
-                    if (A.pqpos[v] == A.bs_id[s]) { cand[nc].v = v; cand[nc].src = a; ++nc; }
+                    if (A.vr[v].pqpos == A.bs_id[s]) { cand[nc].v = v; cand[nc].src = a; ++nc; }
                 }
                 if (nc < Bcur) {
                     for (int32_t oc = A.ocur[b]; oc < A.oend[b] && nc < Bcur; ++oc) {
                         int32_t v = A.orig_order[oc];
-                        if (A.pqpos[v] == -1) { cand[nc].v = v; cand[nc].src = ~oc; ++nc; }
+                        if (A.vr[v].pqpos == -1) { cand[nc].v = v; cand[nc].src = ~oc; ++nc; }
                     }
                 }
                 if (nc > 0) break;
@@ -193,7 +196,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
             if (!use_pq) return;
             int32_t src = cand[P - 1].src;
             if (src >= 0) A.bs_cnt[b] = src; else { A.bs_cnt[b] = 0; A.ocur[b] = (~src) + 1; }
-            for (int32_t i = 0; i < P; ++i) A.pqpos[cand[i].v] = -2;
+            for (int32_t i = 0; i < P; ++i) A.vr[cand[i].v].pqpos = -2;
         };
         auto cleanup = [&]() { for (int32_t i = 0; i < nc; ++i) batch_pos[cand[i].v] = -1; };
         if (Pmax == 0) {
@@ -253,7 +256,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
                 TRes& R = ent_tres(C.e[j]);
                 if (tcount[x] > 1) { R.flags = TF_CONTENDED; cont.push_back({x, i, j}); continue; }
                 int mv, c; bool cx = false;
-                int32_t k2 = cand_replay(A, C, j, use_pq ? A.key[x] : 1, use_pq ? G.n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
+                int32_t k2 = cand_replay(A, C, j, use_pq ? A.vr[x].key : 1, use_pq ? G.n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
                 if (!use_pq) { mv = -1; cx = false; }
                 R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c; R.flags = 0;
                 if (cx) C.flags |= CF_COMPLEX;
@@ -263,7 +266,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
         contended_total += (int64_t)cont.size();
         for (size_t q = 0; q < cont.size();) {
             size_t r = q;
-            int32_t key = use_pq ? A.key[cont[q].x] : 1;
+            int32_t key = use_pq ? A.vr[cont[q].x].key : 1;
             while (r < cont.size() && cont[r].x == cont[q].x) {
                 Cand& C = cand[cont[r].i];
                 bool allow_last = (done + cont[r].i + 1) + 1 < n;
@@ -337,7 +340,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
                     TRes Rr = ent_tres(cand[all[r].i].e[all[r].j]);
                     if (Rr.mv >= 0) { mvseq = (all[r].i << 8) | Rr.mv; break; }
                 }
-                if (R.key_after != A.key[x]) A.key[x] = R.key_after;
+                if (R.key_after != A.vr[x].key) A.vr[x].key = R.key_after;
                 if (mvseq >= 0) moves.push_back({((uint64_t)(uint32_t)pq_list_of(R.key_after, G.n) << 32) | (uint32_t)mvseq, x});
             }
         }
@@ -352,22 +355,22 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
                         if (j == C.koff) continue;
                         int32_t s_r = C.e[j].twin, s_n = pslot[i][j];
                         double nw = C.e[j].val;
-                        A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
-                        A.e_nbr[s_n] = C.e[j].nbr; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+                        A.e[s_r].nbr = k; A.e[s_r].val = nw; A.e[s_r].twin = s_n;
+                        A.e[s_n].nbr = C.e[j].nbr; A.e[s_n].val = nw; A.e[s_n].twin = s_r;
                     }
-                    A.e_val[C.e[C.koff].twin] = 0;
+                    A.e[C.e[C.koff].twin].val = 0;
                 }
             } else {
                 for (int32_t j = 0; j < m - 1; ++j) {
                     int32_t k = C.e[C.ksel[j]].nbr, s_r = C.e[j].twin, s_n = pslot[i][j];
                     if (s_r < 0) s_r = pslot[(~s_r) / BC][(~s_r) % BC];   // patched entry: the slot an earlier candidate of this round appends
                     double nw = C.e[j].val;
-                    A.e_nbr[s_r] = k; A.e_val[s_r] = nw; A.e_twin[s_r] = s_n;
-                    A.e_nbr[s_n] = C.e[j].nbr; A.e_val[s_n] = nw; A.e_twin[s_n] = s_r;
+                    A.e[s_r].nbr = k; A.e[s_r].val = nw; A.e[s_r].twin = s_n;
+                    A.e[s_n].nbr = C.e[j].nbr; A.e[s_n].val = nw; A.e[s_n].twin = s_r;
                 }
-                if (m >= 1) { int32_t s_l = C.e[m - 1].twin; if (s_l < 0) s_l = pslot[(~s_l) / BC][(~s_l) % BC]; A.e_val[s_l] = 0; }
+                if (m >= 1) { int32_t s_l = C.e[m - 1].twin; if (s_l < 0) s_l = pslot[(~s_l) / BC][(~s_l) % BC]; A.e[s_l].val = 0; }
             }
-            for (int32_t q = 0; q < C.nkill; ++q) A.e_val[C.e[m + q].twin] = 0;   // merged multi-edges (:289)
+            for (int32_t q = 0; q < C.nkill; ++q) A.e[C.e[m + q].twin].val = 0;   // merged multi-edges (:289)
             G.n_draws += C.ndraw;
         }
         // PQ pushes in (bucket, op) order
