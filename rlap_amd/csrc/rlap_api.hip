@@ -236,7 +236,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     ENSURE(h->ext, 4 * (S + 1)); ENSURE(h->cnt, 4 * (S + 1)); ENSURE(h->tmp_off, 8 * (S + 1)); ENSURE(h->row_off, 8 * (S + 1));
     ENSURE(h->tmp_nbr, 4 * slot_cap); ENSURE(h->tmp_val, 8 * slot_cap);   // staged rows: at most one per slot in use
     ENSURE(h->sc_rec, sizeof(SRec) * scr_budget); ENSURE(h->sc_i32, 4 * 7 * scr_budget); ENSURE(h->sc_f64, 8 * 2 * scr_budget);
-    ENSURE(h->biglist, 4 * 6 * (S + 1));
+    ENSURE(h->biglist, 4 * 7 * (S + 1));
     ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
     ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
     ENSURE(h->out_ptr_d, 8 * (G + 1));
@@ -292,12 +292,13 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(nnz_p, h->pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), h->idx1.as<uint32_t>(), h->head.as<int32_t>(),
-                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, h->ent.as<Slot>(), h->slot_col.as<int32_t>());
+                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, h->ent.as<Slot>(), h->slot_col.as<int32_t>(),
+                           h->idx0.as<int32_t>());   // (idx0 is free once the sort has run: dense neighbour ids for the twin search)
     }
     hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, h->slot_col.as<int32_t>(), nnz_p, (int32_t)N, h->colptr.as<int32_t>());
     if (Eeff > 0)
         hipLaunchKernelGGL(k_twin_sym, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->ent.as<Slot>(),
-                           h->slot_col.as<int32_t>(), nnz_p, acc);
+                           h->slot_col.as<int32_t>(), h->idx0.as<int32_t>(), nnz_p, acc);
     HIPCHK(hipMemcpyAsync(h->pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
     // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)
     hipLaunchKernelGGL(k_gd_scratch, dim3(1), dim3(256), 0, s, h->colptr.as<int32_t>(), h->node_ptr_d.as<int64_t>(), (int32_t)G, h->gd_d.as<GraphDesc>());
@@ -383,9 +384,9 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = scr_budget; SS.top = counters + 0; SS.flags = flags;
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
     if (S > 0) {
-        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 6 ints: tiers 0..5
+        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 7 ints: tiers 0..6
         if (!h->big_attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIGCAP * 16));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
             h->big_attr_set = true;
         }
         ScLaunch X;

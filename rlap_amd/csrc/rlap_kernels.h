@@ -23,7 +23,10 @@ struct CallResults {
 };
 constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
 constexpr int SCAP = 512;  // output pass: same
-constexpr int BIGCAP = 8192;  // output pass, long columns: one workgroup with a 128 KB LDS record array
+constexpr int BIGCAP = 8000;  // output pass, long columns: one workgroup, 125 KB LDS record array + 31 KB LDS stop lists of the sort
+constexpr int BIG_LDS_BYTES = BIGCAP * 16 + 2 * (BIGCAP + 2) * 2;
+constexpr int MIDCAP = 2048;  // ... columns up to this many slots take a third of that LDS (three workgroups per CU)
+constexpr int MID_LDS_BYTES = MIDCAP * 16 + 2 * (MIDCAP + 2) * 2;
 constexpr int POOL_GRAB_BIG = 16384;   // append slots a 1024-thread workgroup reserves at a time (256-thread: POOL_GRAB_SMALL)
 constexpr int POOL_GRAB_SMALL = 2048;
 constexpr int LIVE_SLOTS = 64;   // the output pass sums its live-entry count into this many counters, LIVE_STRIDE words apart
@@ -82,9 +85,9 @@ __global__ void k_collect(const int32_t* flags, const double* acc, const int32_t
                           const int32_t* pool_top, const int32_t* bs_pool_top, CallResults* out);
 __global__ void k_heads(const uint64_t* keys, int64_t E, int32_t* head);
 __global__ void k_fill_csr(const uint64_t* keys, const uint32_t* idx, const int32_t* head, const int32_t* pos, const double* w,
-                           int64_t E, int set_semantics, Slot* ent, int32_t* slot_col);
+                           int64_t E, int set_semantics, Slot* ent, int32_t* slot_col, int32_t* nbr32);
 __global__ void k_colptr(const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int32_t* colptr);
-__global__ void k_twin_sym(const int32_t* colptr, Slot* ent, const int32_t* slot_col, const int32_t* nnz_p, double* acc);
+__global__ void k_twin_sym(const int32_t* colptr, Slot* ent, const int32_t* slot_col, const int32_t* nbr32, const int32_t* nnz_p, double* acc);
 __global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, VRec* vr, uint64_t* skey, uint32_t* sval);
 __global__ void k_bucket_bounds(const uint32_t* order, const VRec* vr, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
                                 int32_t* ocur, int32_t* oend, int32_t* origpos);
@@ -102,7 +105,7 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
                      unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* biglists, uint16_t* hugelists);
 __global__ void k_debug_wave_sort(const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out);
 __global__ void k_sc_merge_big(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
-                               int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists);
+                               int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists, int32_t lcap);
 __global__ void k_sc_merge_huge(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
                                 int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists, SRec* scratch,
                                 unsigned long long* scratch_top, int64_t scratch_cap, int32_t* flags);

@@ -241,7 +241,7 @@ __global__ void k_heads(const uint64_t* __restrict__ keys, int64_t E, int32_t* _
 
 __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const int32_t* __restrict__ head,
                            const int32_t* __restrict__ pos, const double* __restrict__ w, int64_t E, int set_semantics,
-                           Slot* __restrict__ ent, int32_t* __restrict__ slot_col) {
+                           Slot* __restrict__ ent, int32_t* __restrict__ slot_col, int32_t* __restrict__ nbr32) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E || !head[i]) return;
     uint64_t k = keys[i];
@@ -253,6 +253,7 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
     Slot g; g.val = sum; g.nbr = (int32_t)(k & 0xFFFFFFFFull); g.twin = -1;
     ent[s] = g;
     slot_col[s] = c;
+    nbr32[s] = g.nbr;   // dense copy of the neighbour ids for the twin search (4-byte stride instead of 16)
 }
 
 // colptr[c] = first slot whose column is >= c (slots are sorted by column): no atomics, empty columns included
@@ -272,22 +273,22 @@ __global__ void k_colptr(const int32_t* __restrict__ slot_col, const int32_t* __
 // the isApprox(A^T) test: ||A-A^T||_F^2 <= 1e-24 ||A||_F^2 (Eigen default prec).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ colptr, Slot* __restrict__ ent,
-                                                  const int32_t* __restrict__ slot_col,
+                                                  const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nbr32,
                                                   const int32_t* __restrict__ nnz_p, double* __restrict__ acc) {
     const int32_t nnz = *nnz_p;
     double d2 = 0, n2 = 0;
     bool asym = false;
     for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += gridDim.x * blockDim.x) {
-        int32_t c = slot_col[p], r = ent[p].nbr;
+        int32_t c = slot_col[p], r = nbr32[p];
         double v = ent[p].val;
         n2 += v * v;
         int32_t lo = colptr[r], hi = colptr[r + 1];
         const int32_t end = hi;
         while (lo < hi) {
             int32_t mid = (lo + hi) >> 1;
-            if (ent[mid].nbr < c) lo = mid + 1; else hi = mid;
+            if (nbr32[mid] < c) lo = mid + 1; else hi = mid;
         }
-        if (lo < end && ent[lo].nbr == c) {
+        if (lo < end && nbr32[lo] == c) {
             ent[p].twin = lo;
             double d = v - ent[lo].val;
             d2 += d * d;
@@ -3075,22 +3076,22 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
 // work lists per capacity tier (5: <=32 (two columns per wave), 0: <=64, 1: <=192, 2: <=512 and what the long-column kernels
 // do not take, 3: k_sc_merge_big, 4: k_sc_merge_huge)
 __global__ __launch_bounds__(1024) void k_sc_tierlists(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
-    __shared__ int32_t s_cnt[6], s_base[6];
+    __shared__ int32_t s_cnt[7], s_base[7];
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tier = -1;
     (void)keyed;
-    if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 7) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     if (i < S) {
         int32_t e = ext[i];
-        tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= HUGECAP) ? (e <= BIGCAP ? 3 : 4) : 2));
+        tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= HUGECAP) ? (e <= MIDCAP ? 6 : (e <= BIGCAP ? 3 : 4)) : 2));
     }
     // one LDS atomic per wave and tier, one global atomic per workgroup and tier (same-address atomics serialise):
     // neighbouring columns stay neighbours in the list (locality of the staged rows)
     int32_t my = 0;
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
+    for (int t = 0; t < 7; ++t) {
         uint64_t mk = __ballot(tier == t);
         if (mk == 0ull) continue;
         int32_t base = 0;
@@ -3100,7 +3101,7 @@ __global__ __launch_bounds__(1024) void k_sc_tierlists(const int32_t* __restrict
         if (tier == t) my = base + __popcll(mk & lanemask_lt(lane));
     }
     __syncthreads();
-    if (threadIdx.x < 6 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x < 7 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
     if (tier >= 0) lists[(size_t)tier * S + s_base[tier] + my] = i;
 }
@@ -3244,8 +3245,11 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
     }
     // long columns: whole column in LDS, one single-wave workgroup each; longer than the LDS record array (hubs of
     // weighted graphs): records in global scratch, a few workgroups
-    hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), BIGCAP * 16, s1, A, gd, vgraph, order, ext, tmp_off, lists + 3 * (size_t)S, counts + 3,
-                       tmp_nbr, tmp_val, cnt_out, live_total, biglists);
+    // (one workgroup per CU at 157 KB of LDS: the few columns beyond MIDCAP slots; the many below run three to a CU)
+    hipLaunchKernelGGL(k_sc_merge_big, dim3(512), dim3(64), BIG_LDS_BYTES, s1, A, gd, vgraph, order, ext, tmp_off, lists + 3 * (size_t)S, counts + 3,
+                       tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)BIGCAP);
+    hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), MID_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 6 * (size_t)S, counts + 6,
+                       tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)MIDCAP);
     hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s1, A, gd, vgraph, order, ext, tmp_off, lists + 4 * (size_t)S, counts + 4,
                        tmp_nbr, tmp_val, cnt_out, live_total, hugelists, SS.rec, SS.top, SS.cap, SS.flags);
     unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
@@ -3288,13 +3292,15 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
                                                    const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
                                                    double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
                                                    unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists,
-                                                   Rec2* lds_R, Rec2* glob_R, unsigned long long* glob_top, int64_t glob_cap, int32_t* glob_flags) {
+                                                   Rec2* lds_R, int32_t lds_cap, Rec2* glob_R, unsigned long long* glob_top, int64_t glob_cap, int32_t* glob_flags) {
     constexpr int LCAP = HUGE ? HUGECAP : BIGCAP;
     __shared__ uint32_t s_segmark[LCAP / 32 + 2];
     __shared__ int32_t s_stk[3 * 48];
     __shared__ unsigned long long s_off;
-    // stop lists of the partition emulation: global scratch, one region per workgroup
-    const WaveSortPtrs WP = {lists + (size_t)blockIdx.x * 2 * (LCAP + 2), lists + (size_t)blockIdx.x * 2 * (LCAP + 2) + (LCAP + 2), s_segmark, s_stk};
+    // stop lists of the partition emulation: in LDS behind the records (long columns), in global scratch, one region per
+    // workgroup (huge columns)
+    uint16_t* const mylists = HUGE ? lists + (size_t)blockIdx.x * 2 * (LCAP + 2) : reinterpret_cast<uint16_t*>(lds_R + lds_cap);
+    const WaveSortPtrs WP = {mylists, mylists + ((HUGE ? LCAP : lds_cap) + 2), s_segmark, s_stk};
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     const int32_t nbig = *count;
@@ -3386,9 +3392,9 @@ __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const GraphDesc* 
                                                      const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
                                                      const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
                                                      double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
-                                                     unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists) {
-    extern __shared__ Rec2 R_lds[];   // BIGCAP records
-    sc_merge_long_body<false>(A, gd, vgraph, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, R_lds, nullptr, nullptr, 0, nullptr);
+                                                     unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists, int32_t lcap) {
+    extern __shared__ Rec2 R_lds[];   // lcap records, then the two stop lists of the sort
+    sc_merge_long_body<false>(A, gd, vgraph, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, R_lds, lcap, nullptr, nullptr, 0, nullptr);
 }
 
 __global__ __launch_bounds__(64) void k_sc_merge_huge(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
@@ -3400,7 +3406,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_huge(Arrays A, const GraphDesc*
                                                       SRec* __restrict__ scratch, unsigned long long* __restrict__ scratch_top, int64_t scratch_cap,
                                                       int32_t* __restrict__ flags) {
     static_assert(sizeof(Rec2) == sizeof(SRec), "the long-column records borrow the output pass's record scratch");
-    sc_merge_long_body<true>(A, gd, vgraph, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, nullptr,
+    sc_merge_long_body<true>(A, gd, vgraph, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, nullptr, 0,
                              reinterpret_cast<Rec2*>(scratch), scratch_top, scratch_cap, flags);
 }
 
