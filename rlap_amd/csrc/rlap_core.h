@@ -815,6 +815,9 @@ RLAP_HD void cand_prepare(const Arrays& A, int32_t v, CT& C, int32_t vbase = 0) 
 template <class CT>
 RLAP_HD bool cand_patch(const Arrays& A, CT* cand, int32_t d, int32_t vbase) {
     CT& C = cand[d];
+    // a record with merged multi-edges (64-slot candidates, o_v = random) cannot be patched: WHICH duplicate survived the merge
+    // is std::sort's (unstable) choice over the whole gathered list, and that list would hold k instead of j
+    if (C.nkill > 0) return false;
     for (int32_t q = 0; q < C.ndep; ++q) {
         const int32_t j = C.dep[q];
         const CT& J = cand[j];

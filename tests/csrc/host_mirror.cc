@@ -142,6 +142,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
     int64_t why[6] = {0, 0, 0, 0, 0, 0};
     int64_t adjcase[4] = {0, 0, 0, 0};
     int64_t npatch_try = 0, npatch_ok = 0;
+    const int64_t patch_limit = std::getenv("RLAP_MIRROR_PATCH_LIMIT") ? std::atoll(std::getenv("RLAP_MIRROR_PATCH_LIMIT")) : -1;   // diagnostic: only the first N patches
     const bool patching = (A.o_v != OV_COARSEN) && (std::getenv("RLAP_MIRROR_NO_PATCH") == nullptr);   // first dependent candidate of a round: sampled by an earlier one (moves away), last neighbour (Dec), patchable, patch makes a multi-edge
     int64_t single_len = 0, single_gt384 = 0, single_gt384_len = 0, single_max = 0;  // adjacent, big, dup, complex, pre-empted, full
     std::vector<int32_t> batch_pos((size_t)n, -1), tcount((size_t)n, 0);
@@ -221,7 +222,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
         for (int32_t i = 0; i < Pmax; ++i) {
             if (cand[i].ndep > 0) {
                 ++npatch_try;
-                if (!cand_patch(A, cand.data(), i, G.vbase)) { Pmax = i; Pwhy = (cand[i].flags & CF_DUP) ? 2 : 0; break; }
+                if ((patch_limit >= 0 && npatch_ok >= patch_limit) || !cand_patch(A, cand.data(), i, G.vbase)) { Pmax = i; Pwhy = (cand[i].flags & CF_DUP) ? 2 : 0; break; }
                 ++npatch_ok;
             }
             cand_sample(A, cand[i]);

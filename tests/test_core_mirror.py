@@ -146,3 +146,22 @@ def test_batch_rounds_equal_sequential_order(host_mirror, o_v, o_n):
                     b, ob, _ = _mirror_batch(host_mirror, ei, wts, n, t, o_v, o_n, B, perm=perm, seed=3, bc=bc)
                     assert np.array_equal(oa, ob), (name, t, B, bc)
                     assert a.shape == b.shape and np.array_equal(a, b), (name, t, B, bc)
+
+
+@pytest.mark.parametrize("o_v", ["degree", "random"])
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_patched_dependent_candidates_equal_sequential_order(host_mirror, o_v, o_n):
+    """Round 2 rule (rlap_core.h::cand_patch): a candidate adjacent to an earlier candidate of its round is patched from
+    that one's sampled record instead of cutting the round.  Graphs large enough for the rule to fire hundreds of times,
+    unit and tie-free weights, both candidate widths; bit-exact against the oracle, and the rule really is exercised."""
+    for n, m in ((8000, 10), (3000, 3)):
+        ei = ba_graph(n, m, 7)
+        perm = np.random.RandomState(10).permutation(n) if o_v == "random" else None
+        for wts in (None, sym_weights(ei, n, 5)):
+            a, oa = oracle.approximate_cholesky(ei, wts, n, n // 2, o_v, o_n, perm=perm, shuffle_seed=3, return_order=True)
+            for B, bc in ((128, 32), (64, 64)):
+                b, ob, st = _mirror_batch(host_mirror, ei, wts, n, n // 2, o_v, o_n, B, perm=perm, seed=3, bc=bc)
+                assert np.array_equal(oa, ob), (n, m, B, bc)
+                assert a.shape == b.shape and np.array_equal(a, b), (n, m, B, bc)
+                if o_v == "degree" and bc == 32 and m == 10:
+                    assert st[18] > 20, "the patch rule was not exercised"
