@@ -281,24 +281,37 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     }
     if (G > 1) hipLaunchKernelGGL(k_vertex_graph, dim3(nblk(N, 256)), dim3(256), 0, s, h->node_ptr_d.as<int64_t>(), (int)G, h->vgraph.as<int32_t>(), N);
 
+    const int kbits = (int)bits_for((uint64_t)(N > 1 ? N - 1 : 1));
     if (Eeff > 0) {
         hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_row, c.d_col, c.d_w, E, N, G > 1 ? h->vgraph.as<int32_t>() : (const int32_t*)nullptr,
-                           c.symmetrize, h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), flags);
-        // keys are (col << 32 | row) with ids < N, or all ones for dropped entries (these need the top bit to sort last)
-        int rc = sort_pairs(h, h->keys0.as<uint64_t>(), h->keys1.as<uint64_t>(), h->idx0.as<uint32_t>(), h->idx1.as<uint32_t>(), Eeff, 0, 64);
+                           c.symmetrize, kbits, h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), flags);
+        // keys are (col << kbits | row) with ids < N, or all ones for dropped entries (bit 2 * kbits makes these sort last)
+        int rc = sort_pairs(h, h->keys0.as<uint64_t>(), h->keys1.as<uint64_t>(), h->idx0.as<uint32_t>(), h->idx1.as<uint32_t>(), Eeff, 0,
+                            (unsigned)std::min(64, 2 * kbits + 1));
         if (rc) return rc;
+        { Fills F2; F2.add(h->idx0.p, Eeff, (int32_t)N); F2.launch(s); }   // idx0 becomes the dense row-id array: slots beyond nnz hold N (sorts last)
         hipLaunchKernelGGL(k_heads, dim3(nblk(Eeff + 1, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), Eeff, h->head.as<int32_t>());
         rc = excl_scan(h, h->head.as<int32_t>(), h->pos.as<int32_t>(), Eeff + 1);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(nnz_p, h->pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), h->idx1.as<uint32_t>(), h->head.as<int32_t>(),
-                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, h->ent.as<Slot>(), h->slot_col.as<int32_t>(),
+                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, kbits, h->ent.as<Slot>(), h->slot_col.as<int32_t>(),
                            h->idx0.as<int32_t>());   // (idx0 is free once the sort has run: dense neighbour ids for the twin search)
     }
     hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, h->slot_col.as<int32_t>(), nnz_p, (int32_t)N, h->colptr.as<int32_t>());
-    if (Eeff > 0)
-        hipLaunchKernelGGL(k_twin_sym, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->ent.as<Slot>(),
-                           h->slot_col.as<int32_t>(), h->idx0.as<int32_t>(), nnz_p, acc);
+    if (Eeff > 0) {
+        // twins: stable sort of the slots by row id (keys0 is free again: sorted keys in its first half, the slot order T in its second)
+        uint32_t* skeys = h->keys0.as<uint32_t>();
+        uint32_t* T = skeys + Eeff;
+        size_t bytes = 0;
+        rocprim::counting_iterator<uint32_t> iota(0u);
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->idx0.as<uint32_t>(), skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
+        ENSURE(h->sorttmp, bytes);
+        bytes = h->sorttmp.cap;
+        HIPCHK(rocprim::radix_sort_pairs(h->sorttmp.p, bytes, h->idx0.as<uint32_t>(), skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
+        hipLaunchKernelGGL(k_twin_sorted, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(),
+                           h->slot_col.as<int32_t>(), h->idx0.as<int32_t>(), T, nnz_p, acc);
+    }
     HIPCHK(hipMemcpyAsync(h->pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
     // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)
     hipLaunchKernelGGL(k_gd_scratch, dim3(1), dim3(256), 0, s, h->colptr.as<int32_t>(), h->node_ptr_d.as<int64_t>(), (int32_t)G, h->gd_d.as<GraphDesc>());

@@ -75,7 +75,7 @@ __global__ void k_transpose_copy(const double* in, double* out, int64_t rows, in
 __global__ void k_unpack_edge_info(const double* ei, int64_t E, int64_t* row, int64_t* col, double* w);
 __global__ void k_vertex_graph(const int64_t* node_ptr, int G, int32_t* vgraph, int64_t N);
 __global__ void k_edge_keys(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t N, const int32_t* vgraph,
-                            int symmetrize, uint64_t* keys, uint32_t* idx, int32_t* flags);
+                            int symmetrize, int kbits, uint64_t* keys, uint32_t* idx, int32_t* flags);
 __global__ void k_max_id(const int64_t* row, const int64_t* col, int64_t E, unsigned long long* out);
 __global__ void k_fill_multi(FillJobs J);
 __global__ void k_perm_check(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, int32_t N, int32_t* seen, int32_t* flags);
@@ -85,7 +85,8 @@ __global__ void k_collect(const int32_t* flags, const double* acc, const int32_t
                           const int32_t* pool_top, const int32_t* bs_pool_top, CallResults* out);
 __global__ void k_heads(const uint64_t* keys, int64_t E, int32_t* head);
 __global__ void k_fill_csr(const uint64_t* keys, const uint32_t* idx, const int32_t* head, const int32_t* pos, const double* w,
-                           int64_t E, int set_semantics, Slot* ent, int32_t* slot_col, int32_t* nbr32);
+                           int64_t E, int set_semantics, int kbits, Slot* ent, int32_t* slot_col, int32_t* nbr32);
+__global__ void k_twin_sorted(Slot* ent, const int32_t* slot_col, const int32_t* nbr32, const uint32_t* T, const int32_t* nnz_p, double* acc);
 __global__ void k_colptr(const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int32_t* colptr);
 __global__ void k_twin_sym(const int32_t* colptr, Slot* ent, const int32_t* slot_col, const int32_t* nbr32, const int32_t* nnz_p, double* acc);
 __global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, VRec* vr, uint64_t* skey, uint32_t* sval);

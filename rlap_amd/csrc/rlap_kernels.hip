@@ -115,7 +115,7 @@ __global__ void k_vertex_graph(const int64_t* __restrict__ node_ptr, int G, int3
 // symmetrize != 0: the step before the path (PyG to_undirected, scripts/node_shared.py:326-327) fused in -- every
 // input entry (a,b) also yields (b,a); the duplicates this creates are folded by k_heads / k_fill_csr.
 __global__ void k_edge_keys(const int64_t* __restrict__ row, const int64_t* __restrict__ col, const double* __restrict__ w,
-                            int64_t E, int64_t N, const int32_t* __restrict__ vgraph, int symmetrize, uint64_t* __restrict__ keys,
+                            int64_t E, int64_t N, const int32_t* __restrict__ vgraph, int symmetrize, int kbits, uint64_t* __restrict__ keys,
                             uint32_t* __restrict__ idx, int32_t* __restrict__ flags) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t Eeff = symmetrize ? 2 * E : E;
@@ -129,7 +129,7 @@ __global__ void k_edge_keys(const int64_t* __restrict__ row, const int64_t* __re
         flags[FLAG_RANGE] = 1;
     } else if (wv != 0) {
         if (vgraph && vgraph[r] != vgraph[c]) flags[FLAG_CROSS] = 1;
-        k = ((uint64_t)c << 32) | (uint64_t)r;
+        k = ((uint64_t)c << kbits) | (uint64_t)r;   // kbits = bits of N - 1: the sort only runs over the 2 * kbits + 1 bits that can differ
     }
     keys[p] = k;
     idx[p] = (uint32_t)q;
@@ -240,7 +240,7 @@ __global__ void k_heads(const uint64_t* __restrict__ keys, int64_t E, int32_t* _
 }
 
 __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const int32_t* __restrict__ head,
-                           const int32_t* __restrict__ pos, const double* __restrict__ w, int64_t E, int set_semantics,
+                           const int32_t* __restrict__ pos, const double* __restrict__ w, int64_t E, int set_semantics, int kbits,
                            Slot* __restrict__ ent, int32_t* __restrict__ slot_col, int32_t* __restrict__ nbr32) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= E || !head[i]) return;
@@ -249,11 +249,11 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
     double sum = w ? w[idx[i]] : 1.0;
     // duplicates summed in input order (setFromTriplets); unweighted symmetrised input is an edge SET (PyG coalesce): weight 1
     if (!set_semantics) for (int64_t q = i + 1; q < E && keys[q] == k; ++q) sum += w ? w[idx[q]] : 1.0;
-    int32_t c = (int32_t)(k >> 32);
-    Slot g; g.val = sum; g.nbr = (int32_t)(k & 0xFFFFFFFFull); g.twin = -1;
+    int32_t c = (int32_t)(k >> kbits);
+    Slot g; g.val = sum; g.nbr = (int32_t)(k & ((1ull << kbits) - 1ull)); g.twin = -1;
     ent[s] = g;
     slot_col[s] = c;
-    nbr32[s] = g.nbr;   // dense copy of the neighbour ids for the twin search (4-byte stride instead of 16)
+    nbr32[s] = g.nbr;   // dense copy of the row ids: key of the sort that finds the twins (k_twin_sorted)
 }
 
 // colptr[c] = first slot whose column is >= c (slots are sorted by column): no atomics, empty columns included
@@ -305,6 +305,44 @@ __global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ co
     if ((threadIdx.x & 63) == 0) { sd[w] = d2; sn[w] = n2; }
     __syncthreads();
     if (threadIdx.x == 0) {   // one pair of atomics per block (the grid is a few thousand blocks: same-address atomics serialise)
+        const double bd = sd[0] + sd[1] + sd[2] + sd[3], bn = sn[0] + sn[1] + sn[2] + sn[3];
+        if (bd != 0.0) atomicAdd(&acc[0], bd);
+        if (bn != 0.0) atomicAdd(&acc[1], bn);
+    }
+}
+
+// The same from a sort instead of a search per entry.  The slots are in (col, row) order; a STABLE sort of the slots by
+// row alone puts them in (row, col) order: T[k] = slot holding the k-th smallest (row, col) pair.  For a symmetric
+// pattern that pair is the transpose of the k-th smallest (col, row) pair, i.e. of slot k: twin[k] = T[k].  Any slot whose
+// partner does not hold the transposed ids proves the pattern asymmetric.  (One radix sort of 4-byte keys over bits_for(N)
+// bits and two gathers per entry instead of log2(degree) dependent probes.)
+__global__ __launch_bounds__(256) void k_twin_sorted(Slot* __restrict__ ent, const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nbr32,
+                                                     const uint32_t* __restrict__ T, const int32_t* __restrict__ nnz_p, double* __restrict__ acc) {
+    const int32_t nnz = *nnz_p;
+    double d2 = 0, n2 = 0;
+    bool asym = false;
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += gridDim.x * blockDim.x) {
+        const int32_t c = slot_col[p], r = nbr32[p];
+        const double v = ent[p].val;
+        n2 += v * v;
+        const uint32_t q = T[p];
+        if (q < (uint32_t)nnz && nbr32[q] == c && slot_col[q] == r) {
+            ent[p].twin = (int32_t)q;
+            const double d = v - ent[q].val;
+            d2 += d * d;
+        } else {
+            ent[p].twin = -1;
+            d2 += 2 * v * v;
+            asym = true;
+        }
+    }
+    if (asym) acc[2] = 1.0;  // structurally asymmetric
+    for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off); n2 += __shfl_down(n2, off); }
+    __shared__ double sd[4], sn[4];
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sd[w] = d2; sn[w] = n2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         const double bd = sd[0] + sd[1] + sd[2] + sd[3], bn = sn[0] + sn[1] + sn[2] + sn[3];
         if (bd != 0.0) atomicAdd(&acc[0], bd);
         if (bn != 0.0) atomicAdd(&acc[1], bn);
