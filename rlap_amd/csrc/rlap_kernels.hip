@@ -2173,33 +2173,37 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 //      dependent candidates takes one pass of this loop per link).  What cannot be patched cuts the round. ----
                 int32_t* const ptmp = reinterpret_cast<int32_t*>(L.cont) + (tid >> 6) * 160;   // the record lists are idle until the replay
                 static_assert(sizeof(CRec) * CCAP * 2 >= (size_t)NWAVE * 160 * 4, "sort scratch of the patching waves fits the record lists");
-                int32_t Pcur = Pmax;
-                while (true) {
-                    bool progress = false;
-                    #pragma unroll 1
-                    for (int32_t i = (tid >> 6); i < Pcur; i += NWAVE) {
-                        Cand& C = L.cand[i];
-                        const int32_t nd = C.ndep;
-                        if (nd == 0 || (C.flags & (CF_PATCHED | CF_DEP))) continue;     // (wave-uniform)
-                        bool ready = true, lost = false;
-                        for (int32_t q = 0; q < nd && q < DEPMAX; ++q) {
-                            const Cand& J = L.cand[C.dep[q]];
-                            if (J.ndep != 0) { if (J.flags & CF_DEP) lost = true; else if (!(J.flags & CF_PATCHED)) ready = false; }
+                // No workgroup barrier per link of a chain: a wave takes its candidates in increasing order and spins on the flags of
+                // the (smaller) dependent candidates it needs; the smallest unresolved one can always proceed, so every wave gets through.
+                #pragma unroll 1
+                for (int32_t i = (tid >> 6); i < Pmax; i += NWAVE) {
+                    Cand& C = L.cand[i];
+                    const int32_t nd = C.ndep;
+                    if (nd == 0) continue;     // (wave-uniform)
+                    bool lost = false;
+                    for (int32_t q = 0; q < nd && q < DEPMAX; ++q) {
+                        Cand& J = L.cand[C.dep[q]];
+                        if (J.ndep == 0) continue;
+                        volatile int32_t* fp = &J.flags;
+                        int32_t f = *fp, spins = 0;
+                        while (!(f & (CF_PATCHED | CF_DEP))) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > (1 << 20)) { f = CF_DEP; break; }   // (never seen; a stuck wave must not hang the device)
+                            f = *fp;
                         }
-                        if (lost) { if (lane == 0) { atomicOr(&C.flags, CF_DEP); atomicMin(&s_pmax, i); } progress = true; continue; }   // behind a cut
-                        if (!ready) continue;
-                        Arrays A3 = A;
-                        const bool okp = wave_patch<ON>(A3, L.cand, i, G.vbase, ptmp);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) {
-                            if (okp) { atomicOr(&C.flags, CF_PATCHED); s_npatched = 1; }
-                            else { atomicOr(&C.flags, CF_DEP); atomicMin(&s_pmax, i); }
-                        }
-                        progress = true;
+                        if (f & CF_DEP) lost = true;
                     }
-                    if (!__syncthreads_or(progress ? 1 : 0)) break;
-                    Pcur = s_pmax < Pcur ? s_pmax : Pcur;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (i >= *(volatile int32_t*)&s_pmax) lost = true;     // behind a cut already
+                    bool okp = false;
+                    if (!lost) { Arrays A3 = A; okp = wave_patch<ON>(A3, L.cand, i, G.vbase, ptmp); }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) {
+                        if (okp) { atomicOr(&C.flags, CF_PATCHED); s_npatched = 1; }
+                        else { atomicOr(&C.flags, CF_DEP); atomicMin(&s_pmax, i); }
+                    }
                 }
+                __syncthreads();
                 Pmax = s_pmax < Pmax ? s_pmax : Pmax;
             } }
             PHASE_STAMP(19);
