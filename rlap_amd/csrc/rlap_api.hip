@@ -441,6 +441,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         for (int k = 0; k < 20; ++k) std::fprintf(stderr, "  %-22s %10.3f ms\n", names[k], pr[k] / 1e5);
         const char* wnames[9] = {"gather", "sort by id", "merge", "meta loads + order", "cumsum + recurrence", "sample", "replay + slots", "rewire", "pq commit"};
         for (int k = 0; k < 9; ++k) std::fprintf(stderr, "  single/wave: %-20s %10.3f ms\n", wnames[k], pr[24 + k] / 1e5);
+        const char* xnames[5] = {"P4.1 hash insert + key loads", "P4.2 replay (uncontended)", "P4.3 sort of the contended records", "P4.4 contended walk", "P5b uncontended slots (rest of P5b = contended walk)"};
+        for (int k = 0; k < 5; ++k) std::fprintf(stderr, "  detail: %-52s %10.3f ms\n", xnames[k], pr[33 + k] / 1e5);
     }
 
     st.nnz = R.nnz;

@@ -2229,6 +2229,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 }
             }
             __syncthreads();
+            PHASE_STAMP(33);
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
@@ -2263,6 +2264,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 }
             }
             __syncthreads();
+            PHASE_STAMP(34);
             // contended records: order by (x, i) with a rank sort (keys are distinct), then replay each group in order
             const int32_t ncont = s_ncont < CCAP ? s_ncont : CCAP;
             CRec* csorted = L.csorted;
@@ -2277,6 +2279,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 csorted[rank] = me;
             }
             __syncthreads();
+            PHASE_STAMP(35);
             for (int32_t q = tid; q < ncont; q += NT) {
                 if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;   // group head only
                 int32_t x = csorted[q].x;
@@ -2299,6 +2302,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
             }
             __syncthreads();
             // ================= P: the first pre-empting / complex candidate was noted during the replay; bound the
+            PHASE_STAMP(36);
             // number of moves (candidates sit in the first two waves: a wave scan and one word through LDS) =================
             {
                 const int mycnt = tid < Pmax ? L.cand[tid].nmv : 0;
@@ -2473,6 +2477,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 }
             }
         }
+        PHASE_STAMP(37);
         // targets shared by several candidates: one thread walks the target's records in candidate order
         {
             const int32_t ncont = ncont_c;   // <= CCAP < NT: one record per thread
