@@ -236,7 +236,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     ENSURE(h->ext, 4 * (S + 1)); ENSURE(h->cnt, 4 * (S + 1)); ENSURE(h->tmp_off, 8 * (S + 1)); ENSURE(h->row_off, 8 * (S + 1));
     ENSURE(h->tmp_nbr, 4 * slot_cap); ENSURE(h->tmp_val, 8 * slot_cap);   // staged rows: at most one per slot in use
     ENSURE(h->sc_rec, sizeof(SRec) * scr_budget); ENSURE(h->sc_i32, 4 * 7 * scr_budget); ENSURE(h->sc_f64, 8 * 2 * scr_budget);
-    ENSURE(h->biglist, 4 * 7 * (S + 1));
+    ENSURE(h->biglist, 4 * 8 * (S + 1));
     ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
     ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
     ENSURE(h->out_ptr_d, 8 * (G + 1));
@@ -397,7 +397,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = scr_budget; SS.top = counters + 0; SS.flags = flags;
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
     if (S > 0) {
-        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 7 ints: tiers 0..6
+        int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 8 ints: tiers 0..7
         if (!h->big_attr_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
             h->big_attr_set = true;

@@ -27,6 +27,8 @@ constexpr int BIGCAP = 8000;  // output pass, long columns: one workgroup, 125 K
 constexpr int BIG_LDS_BYTES = BIGCAP * 16 + 2 * (BIGCAP + 2) * 2;
 constexpr int MIDCAP = 2048;  // ... columns up to this many slots take a third of that LDS (three workgroups per CU)
 constexpr int MID_LDS_BYTES = MIDCAP * 16 + 2 * (MIDCAP + 2) * 2;
+constexpr int MID1CAP = 1024;  // ... and up to this many a sixth (seven per CU)
+constexpr int MID1_LDS_BYTES = MID1CAP * 16 + 2 * (MID1CAP + 2) * 2;
 constexpr int POOL_GRAB_BIG = 16384;   // append slots a 1024-thread workgroup reserves at a time (256-thread: POOL_GRAB_SMALL)
 constexpr int POOL_GRAB_SMALL = 2048;
 constexpr int LIVE_SLOTS = 64;   // the output pass sums its live-entry count into this many counters, LIVE_STRIDE words apart

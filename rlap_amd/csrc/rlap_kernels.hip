@@ -3123,22 +3123,22 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
 // work lists per capacity tier (5: <=32 (two columns per wave), 0: <=64, 1: <=192, 2: <=512 and what the long-column kernels
 // do not take, 3: k_sc_merge_big, 4: k_sc_merge_huge)
 __global__ __launch_bounds__(1024) void k_sc_tierlists(const int32_t* __restrict__ ext, int32_t S, int32_t keyed, int32_t* __restrict__ lists, int32_t* __restrict__ counts) {
-    __shared__ int32_t s_cnt[7], s_base[7];
+    __shared__ int32_t s_cnt[8], s_base[8];
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tier = -1;
     (void)keyed;
-    if (threadIdx.x < 7) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 8) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     if (i < S) {
         int32_t e = ext[i];
-        tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= HUGECAP) ? (e <= MIDCAP ? 6 : (e <= BIGCAP ? 3 : 4)) : 2));
+        tier = e <= 32 ? 5 : e <= 64 ? 0 : (e <= 192 ? 1 : ((e > SCAP && e <= HUGECAP) ? (e <= MID1CAP ? 7 : (e <= MIDCAP ? 6 : (e <= BIGCAP ? 3 : 4))) : 2));
     }
     // one LDS atomic per wave and tier, one global atomic per workgroup and tier (same-address atomics serialise):
     // neighbouring columns stay neighbours in the list (locality of the staged rows)
     int32_t my = 0;
 #pragma unroll
-    for (int t = 0; t < 7; ++t) {
+    for (int t = 0; t < 8; ++t) {
         uint64_t mk = __ballot(tier == t);
         if (mk == 0ull) continue;
         int32_t base = 0;
@@ -3148,7 +3148,7 @@ __global__ __launch_bounds__(1024) void k_sc_tierlists(const int32_t* __restrict
         if (tier == t) my = base + __popcll(mk & lanemask_lt(lane));
     }
     __syncthreads();
-    if (threadIdx.x < 7 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x < 8 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
     if (tier >= 0) lists[(size_t)tier * S + s_base[tier] + my] = i;
 }
@@ -3297,6 +3297,8 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
                        tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)BIGCAP);
     hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), MID_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 6 * (size_t)S, counts + 6,
                        tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)MIDCAP);
+    hipLaunchKernelGGL(k_sc_merge_big, dim3(2048), dim3(64), MID1_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 7 * (size_t)S, counts + 7,
+                       tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)MID1CAP);
     hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s1, A, gd, vgraph, order, ext, tmp_off, lists + 4 * (size_t)S, counts + 4,
                        tmp_nbr, tmp_val, cnt_out, live_total, hugelists, SS.rec, SS.top, SS.cap, SS.flags);
     unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
