@@ -1540,10 +1540,11 @@ __device__ __noinline__ void cand_order_index_call(const Arrays& A, CT& C) { can
 // (ids are distinct), by o_n with the half-wave std::sort restatement.  Returns false when d cannot be patched.
 template <int ON, class CT>
 __device__ __noinline__ bool wave_patch(const Arrays& A, CT* cand, int32_t d, int32_t vbase, int32_t* tmp_wave) {
-    static_assert(CT::CAP == 32, "one entry per lane of a half-wave");
+    static_assert(CT::CAP == 32 || CT::CAP == 64, "one entry per lane");
     const int lane = lane_id();
     CT& C = cand[d];
     const int32_t m = C.m, nd = C.ndep, v = C.v;
+    if (C.nkill > 0) return false;   // merged multi-edges (64-slot candidates): see rlap_core.h::cand_patch
     int32_t my_nbr = lane < m ? C.e[lane].nbr : -1;
     double my_val = lane < m ? C.e[lane].val : 0.0;
     int32_t my_twin = lane < m ? C.e[lane].twin : 0;
@@ -1584,10 +1585,15 @@ __device__ __noinline__ bool wave_patch(const Arrays& A, CT* cand, int32_t d, in
     // order by o_n (:295-307) with std::sort semantics
     constexpr bool keyed = (ON == ON_RANDOM);
     double key = keyed ? keyed_order_dkey(keyed_order_base(A.shuffle_seed, v - vbase, 0), my_nbr - vbase) : my_val;
-    int idx = lane & 31, pos = lane & 31;
-    const bool want = lane < 32 && m > 1;
-    const bool okg = (ON == ON_DESC) ? group_sort<true, 32>(key, idx, m, want, lane, tmp_wave, &pos) : group_sort<false, 32>(key, idx, m, want, lane, tmp_wave, &pos);
-    if (__ballot(want && !okg) != 0ull) return false;   // depth limit of the introsort: leave it to the single-vertex path (conservative)
+    int idx = lane & (CT::CAP - 1), pos = lane & (CT::CAP - 1);
+    if (CT::CAP == 32) {
+        const bool want = lane < 32 && m > 1;
+        const bool okg = (ON == ON_DESC) ? group_sort<true, 32>(key, idx, m, want, lane, tmp_wave, &pos) : group_sort<false, 32>(key, idx, m, want, lane, tmp_wave, &pos);
+        if (__ballot(want && !okg) != 0ull) return false;   // depth limit of the introsort: leave it to the single-vertex path (conservative)
+    } else if (m > 1) {
+        const bool okg = (ON == ON_DESC) ? wave_sort64<true>(key, idx, m, lane, tmp_wave, &pos) : wave_sort64<false>(key, idx, m, lane, tmp_wave, &pos);
+        if (!okg) return false;
+    }
     {
         const int32_t nb = __shfl(my_nbr, idx), tw = __shfl(my_twin, idx);
         const double vv = __shfl(my_val, idx);
@@ -1629,7 +1635,10 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     typedef CandT<BC> Cand;
     typedef BatchLdsT<BC, NTT> BatchLds;
     constexpr bool MERGE = (BC == 64 && OV == OV_RANDOM);           // multi-edges merged inside the candidate (rlap_core.h::cand_merges_multi_edges)
-    constexpr bool PATCH = (BC == 32 && OV == OV_DEGREE);           // candidates adjacent to earlier ones of the round are patched in LDS (rlap_core.h::cand_patch)
+    // candidates adjacent to earlier ones of the round are patched in LDS (rlap_core.h::cand_patch).  Measured: pays for the degree
+    // order (C3 369 -> 274 ms); with o_v = random (64-slot candidates; wave_patch handles them too) the rounds of config 5 get 6.5 %
+    // fewer and no faster, and the coarsening order fills its rounds without it -- so only the degree order uses it.
+    constexpr bool PATCH = (OV == OV_DEGREE);
     constexpr int GSH = 64 - BC;                                  // lane & GSH = first lane of my group
     constexpr uint64_t GMASK = BC == 64 ? ~0ull : 0xFFFFFFFFull;   // a group's part of a 64-bit ballot
     Arrays A = A_in;
