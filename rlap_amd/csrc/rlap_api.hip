@@ -237,7 +237,6 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     ENSURE(h->tmp_nbr, 4 * slot_cap); ENSURE(h->tmp_val, 8 * slot_cap);   // staged rows: at most one per slot in use
     ENSURE(h->sc_rec, sizeof(SRec) * scr_budget); ENSURE(h->sc_i32, 4 * 7 * scr_budget); ENSURE(h->sc_f64, 8 * 2 * scr_budget);
     ENSURE(h->biglist, 4 * 8 * (S + 1));
-    ENSURE(h->biglists, (size_t)1024 * 2 * (BIGCAP + 2) * sizeof(uint16_t));
     ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
     ENSURE(h->out_ptr_d, 8 * (G + 1));
     const size_t res_bytes = sizeof(CallResults) + 8 * (size_t)(G + 1);

@@ -2,7 +2,7 @@
 //
 //   K10 k_mt19937_64_table   sampling stream of preconditioner.cc:356-357
 //   K1  k_edge_keys/k_heads/k_fill_csr   COO -> CSR  (reader.cc:42-61)
-//   K2+K3 k_twin_sym         symmetry check + twin index (factorizers.cc:19-22,
+//   K2+K3 k_twin_sorted      symmetry check + twin index (factorizers.cc:19-22,
 //                            preconditioner.cc:22-49)
 //   K4  k_pq_init/k_bucket_bounds  bucket queue (preconditioner.cc:125-165)
 //   K5-K8 k_eliminate_batch_t<o_v,o_n,slots,threads>  one workgroup per graph, rounds of independent
@@ -269,49 +269,10 @@ __global__ void k_colptr(const int32_t* __restrict__ slot_col, const int32_t* __
 }
 
 // ---------------------------------------------------------------------------
-// K2 + K3: twin index by binary search in the neighbour's (sorted) segment and
+// K2 + K3: twin index (from one stable sort of the slots by row id) and
 // the isApprox(A^T) test: ||A-A^T||_F^2 <= 1e-24 ||A||_F^2 (Eigen default prec).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_twin_sym(const int32_t* __restrict__ colptr, Slot* __restrict__ ent,
-                                                  const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nbr32,
-                                                  const int32_t* __restrict__ nnz_p, double* __restrict__ acc) {
-    const int32_t nnz = *nnz_p;
-    double d2 = 0, n2 = 0;
-    bool asym = false;
-    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += gridDim.x * blockDim.x) {
-        int32_t c = slot_col[p], r = nbr32[p];
-        double v = ent[p].val;
-        n2 += v * v;
-        int32_t lo = colptr[r], hi = colptr[r + 1];
-        const int32_t end = hi;
-        while (lo < hi) {
-            int32_t mid = (lo + hi) >> 1;
-            if (nbr32[mid] < c) lo = mid + 1; else hi = mid;
-        }
-        if (lo < end && nbr32[lo] == c) {
-            ent[p].twin = lo;
-            double d = v - ent[lo].val;
-            d2 += d * d;
-        } else {
-            ent[p].twin = -1;
-            d2 += 2 * v * v;
-            asym = true;
-        }
-    }
-    if (asym) acc[2] = 1.0;  // structurally asymmetric
-    for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off); n2 += __shfl_down(n2, off); }
-    __shared__ double sd[4], sn[4];
-    int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sd[w] = d2; sn[w] = n2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {   // one pair of atomics per block (the grid is a few thousand blocks: same-address atomics serialise)
-        const double bd = sd[0] + sd[1] + sd[2] + sd[3], bn = sn[0] + sn[1] + sn[2] + sn[3];
-        if (bd != 0.0) atomicAdd(&acc[0], bd);
-        if (bn != 0.0) atomicAdd(&acc[1], bn);
-    }
-}
-
-// The same from a sort instead of a search per entry.  The slots are in (col, row) order; a STABLE sort of the slots by
+// Twins from a sort instead of a search per entry.  The slots are in (col, row) order; a STABLE sort of the slots by
 // row alone puts them in (row, col) order: T[k] = slot holding the k-th smallest (row, col) pair.  For a symmetric
 // pattern that pair is the transpose of the k-th smallest (col, row) pair, i.e. of slot k: twin[k] = T[k].  Any slot whose
 // partner does not hold the transposed ids proves the pattern asymmetric.  (One radix sort of 4-byte keys over bits_for(N)
