@@ -399,6 +399,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 8 ints: tiers 0..7
         if (!h->big_attr_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_big), hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_mw<8>), hipFuncAttributeMaxDynamicSharedMemorySize, MW_BIG_LDS_BYTES));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_merge_mw<4>), hipFuncAttributeMaxDynamicSharedMemorySize, MW_MID_LDS_BYTES));
             h->big_attr_set = true;
         }
         ScLaunch X;

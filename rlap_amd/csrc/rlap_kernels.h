@@ -23,10 +23,14 @@ struct CallResults {
 };
 constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
 constexpr int SCAP = 512;  // output pass: same
-constexpr int BIGCAP = 8000;  // output pass, long columns: one workgroup, 125 KB LDS record array + 31 KB LDS stop lists of the sort
+constexpr int BIGCAP = 7168;  // output pass, long columns: one workgroup, 125 KB LDS record array + 31 KB LDS stop lists of the sort
 constexpr int BIG_LDS_BYTES = BIGCAP * 16 + 2 * (BIGCAP + 2) * 2;
 constexpr int MIDCAP = 2048;  // ... columns up to this many slots take a third of that LDS (three workgroups per CU)
 constexpr int MID_LDS_BYTES = MIDCAP * 16 + 2 * (MIDCAP + 2) * 2;
+// multi-wave variant (k_sc_merge_mw): records + stop lists + two segment queues of the level-by-level introsort
+constexpr int MW_BIG_QCAP = BIGCAP / 17 + 8, MW_MID_QCAP = MIDCAP / 17 + 8;
+constexpr int MW_BIG_LDS_BYTES = BIGCAP * 16 + 2 * (BIGCAP + 2) * 2 + 8 + 2 * 3 * MW_BIG_QCAP * 4;
+constexpr int MW_MID_LDS_BYTES = MIDCAP * 16 + 2 * (MIDCAP + 2) * 2 + 8 + 2 * 3 * MW_MID_QCAP * 4;
 constexpr int MID1CAP = 1024;  // ... and up to this many a sixth (seven per CU)
 constexpr int MID1_LDS_BYTES = MID1CAP * 16 + 2 * (MID1CAP + 2) * 2;
 constexpr int POOL_GRAB_BIG = 16384;   // append slots a 1024-thread workgroup reserves at a time (256-thread: POOL_GRAB_SMALL)
@@ -102,6 +106,10 @@ __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, cons
 __global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const VRec* vr, int32_t S, int32_t* ext);
 constexpr unsigned NHUGE = 32;   // workgroups of k_sc_merge_huge
 struct ScLaunch { hipStream_t main; hipStream_t side[2]; hipEvent_t ev[3]; };   // side streams may be null: everything on `main`
+template <int NW>
+__global__ void k_sc_merge_mw(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off,
+                              const int32_t* list, const int32_t* count, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out,
+                              unsigned long long* live_total, int32_t lcap, int32_t qcap);
 void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
                      unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* biglists, uint16_t* hugelists);

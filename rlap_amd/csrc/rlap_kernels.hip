@@ -3262,11 +3262,11 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
     }
     // long columns: whole column in LDS, one single-wave workgroup each; longer than the LDS record array (hubs of
     // weighted graphs): records in global scratch, a few workgroups
-    // (one workgroup per CU at 157 KB of LDS: the few columns beyond MIDCAP slots; the many below run three to a CU)
-    hipLaunchKernelGGL(k_sc_merge_big, dim3(512), dim3(64), BIG_LDS_BYTES, s1, A, gd, vgraph, order, ext, tmp_off, lists + 3 * (size_t)S, counts + 3,
-                       tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)BIGCAP);
-    hipLaunchKernelGGL(k_sc_merge_big, dim3(1024), dim3(64), MID_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 6 * (size_t)S, counts + 6,
-                       tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)MIDCAP);
+    // (one workgroup of 8 waves per CU at ~156 KB of LDS: the few columns beyond MIDCAP slots; the tier below: 4 waves, three to a CU)
+    hipLaunchKernelGGL((k_sc_merge_mw<8>), dim3(512), dim3(512), MW_BIG_LDS_BYTES, s1, A, gd, vgraph, order, ext, tmp_off, lists + 3 * (size_t)S, counts + 3,
+                       tmp_nbr, tmp_val, cnt_out, live_total, (int32_t)BIGCAP, (int32_t)MW_BIG_QCAP);
+    hipLaunchKernelGGL((k_sc_merge_mw<4>), dim3(1024), dim3(256), MW_MID_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 6 * (size_t)S, counts + 6,
+                       tmp_nbr, tmp_val, cnt_out, live_total, (int32_t)MIDCAP, (int32_t)MW_MID_QCAP);
     hipLaunchKernelGGL(k_sc_merge_big, dim3(2048), dim3(64), MID1_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 7 * (size_t)S, counts + 7,
                        tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)MID1CAP);
     hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s1, A, gd, vgraph, order, ext, tmp_off, lists + 4 * (size_t)S, counts + 4,
@@ -3414,6 +3414,252 @@ __global__ __launch_bounds__(64) void k_sc_merge_big(Arrays A, const GraphDesc* 
                                                      unsigned long long* __restrict__ live_total, uint16_t* __restrict__ lists, int32_t lcap) {
     extern __shared__ Rec2 R_lds[];   // lcap records, then the two stop lists of the sort
     sc_merge_long_body<false>(A, gd, vgraph, order, ext, tmp_off, list, count, tmp_nbr, tmp_val, cnt_out, live_total, lists, R_lds, lcap, nullptr, nullptr, 0, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// The same restatement of std::sort for ONE array shared by several waves (long surviving columns).  The introsort loop is
+// run level by level: every segment longer than 16 that exists at a level is partitioned by one wave (the wave-parallel
+// Hoare partition of wave_std_sort, its stop lists kept at the segment's own offsets), its two parts are queued for the next
+// level or marked as final; a workgroup barrier separates the levels.  The order in which segments are partitioned does not
+// matter (they are disjoint and std::sort's recursion treats them independently), so the permutation is std::sort's.
+// The final insertion sort (independent stable sorts of the marked segments) is spread over all threads.
+// segq: two queues of QCAP segments (first, last, depth); qcnt[2]; segmark: (n+31)/32+1 words.
+// ---------------------------------------------------------------------------
+template <class T, class Less, int NW>
+__device__ void block_std_sort(T* a, const int n, Less less, uint16_t* ulist, uint16_t* dlist, uint32_t* segmark, int32_t* segq, int32_t* qcnt, const int QCAP) {
+    constexpr int NTB = NW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt = lanemask_lt(lane);
+    for (int q = tid; q < (n + 31) / 32 + 1; q += NTB) segmark[q] = 0u;
+    if (tid == 0) {
+        int depth0 = 0;
+        for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+        qcnt[0] = n > 16 ? 1 : 0; qcnt[1] = 0;
+        segq[0] = 0; segq[1] = n; segq[2] = 2 * depth0;
+    }
+    __syncthreads();
+    if (n < 2) return;
+    if (n <= 16) {
+        if (tid == 0) gs_insertion_sort<T>(a, n, less);
+        __syncthreads();
+        return;
+    }
+    int cur = 0;
+    while (true) {
+        const int ncur = qcnt[cur];
+        if (ncur == 0) break;
+        int32_t* const qin = segq + cur * 3 * QCAP;
+        int32_t* const qout = segq + (cur ^ 1) * 3 * QCAP;
+        for (int sidx = wave; sidx < ncur; sidx += NW) {
+            const int first = qin[3 * sidx], last = qin[3 * sidx + 1];
+            int depth = qin[3 * sidx + 2];
+            if (depth == 0) {   // depth limit: heap sort (std::__partial_sort), by one lane; the segment stays one sorted run
+                if (lane == 0) { gs_heap_sort<T>(a, first, last, less); atomicOr(&segmark[first >> 5], 1u << (first & 31)); }
+                WAVE_SYNC();
+                continue;
+            }
+            --depth;
+            if (lane == 0) {   // __move_median_to_first(first, first+1, mid, last-1)
+                int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                int pick;
+                if (less(a[ia], a[ib])) {
+                    if (less(a[ib], a[ic])) pick = ib;
+                    else if (less(a[ia], a[ic])) pick = ic;
+                    else pick = ia;
+                } else if (less(a[ia], a[ic])) pick = ia;
+                else if (less(a[ib], a[ic])) pick = ic;
+                else pick = ib;
+                T t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            WAVE_SYNC();
+            const T pv = a[first];
+            uint16_t* const ul = ulist + first;
+            uint16_t* const dl = dlist + first;
+            int nu = 0, nd = 0;
+            for (int p0 = first + 1; p0 < last; p0 += 64) {
+                int p = p0 + lane;
+                bool stop = (p < last) && !less(a[p], pv);
+                uint64_t mk = __ballot(stop);
+                if (stop) ul[nu + popc64(mk & lt)] = (uint16_t)p;
+                nu += popc64(mk);
+            }
+            for (int p0 = last - 1; p0 > first; p0 -= 64) {
+                int p = p0 - lane;
+                bool stop = (p > first) && !less(pv, a[p]);
+                uint64_t mk = __ballot(stop);
+                if (stop) dl[nd + popc64(mk & lt)] = (uint16_t)p;
+                nd += popc64(mk);
+            }
+            if (lane == 0) dl[nd] = (uint16_t)first;   // the pivot itself stops the down-scan
+            WAVE_SYNC();
+            int k = 0;
+            {
+                const int tmax = nu < nd ? nu : nd;
+                bool open = true;
+                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
+                    int t = t0 + lane;
+                    bool ok = (t < tmax) && (ul[t] < dl[t]);
+                    uint64_t mk = __ballot(ok);
+                    uint64_t inv = ~mk;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    k += run;
+                    open = (run == 64);
+                }
+            }
+            T xu, xd;
+            for (int t0 = 0; t0 < k; t0 += 64) {
+                int t = t0 + lane;
+                if (t < k) { xu = a[ul[t]]; xd = a[dl[t]]; }
+                WAVE_SYNC();
+                if (t < k) { a[ul[t]] = xd; a[dl[t]] = xu; }
+                WAVE_SYNC();
+            }
+            int cut;
+            {
+                int cu = (k < nu) ? (int)ul[k] : 0x7FFFFFFF;
+                int cd = (k > 0) ? (int)dl[k - 1] : 0x7FFFFFFF;
+                cut = cu < cd ? cu : cd;
+            }
+            WAVE_SYNC();
+            if (lane == 0) {
+                // [first, cut) and [cut, last): longer than 16 -> next level, else a final segment (marked at its start)
+                if (cut - first > 16) { const int qi = atomicAdd(&qcnt[cur ^ 1], 1); qout[3 * qi] = first; qout[3 * qi + 1] = cut; qout[3 * qi + 2] = depth; }
+                else atomicOr(&segmark[first >> 5], 1u << (first & 31));
+                if (last - cut > 16) { const int qi = atomicAdd(&qcnt[cur ^ 1], 1); qout[3 * qi] = cut; qout[3 * qi + 1] = last; qout[3 * qi + 2] = depth; }
+                else if (cut < last) atomicOr(&segmark[cut >> 5], 1u << (cut & 31));
+            }
+            WAVE_SYNC();
+        }
+        __syncthreads();
+        if (tid == 0) qcnt[cur] = 0;
+        cur ^= 1;
+        __syncthreads();
+    }
+    // final insertion sort: thread t takes the segments that start in the 32-position words t, t+NTB, ...
+    for (int w0 = tid; w0 * 32 < n; w0 += NTB) {
+        uint32_t bits = segmark[w0];
+        while (bits) {
+            const int s0 = w0 * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            int e0 = n;
+            if (bits) e0 = w0 * 32 + __builtin_ctz(bits);
+            else {
+                for (int w1 = w0 + 1; w1 * 32 < n; ++w1) { uint32_t bb = segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } }
+            }
+            if (e0 > n) e0 = n;
+            for (int i = s0 + 1; i < e0; ++i) {
+                T v = a[i];
+                int j = i - 1;
+                while (j >= s0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
+                a[j + 1] = v;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Long surviving columns with several waves per column: gather (all threads, traversal order kept by a prefix count), sort by
+// id, merge, order by o_n, store -- the two sorts are block_std_sort.  NW waves, records + stop lists + segment queues in
+// dynamic LDS: lcap * 16 + 2 * (lcap + 2) * 2 + 2 * 3 * QCAP * 4 bytes.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_sc_merge_mw(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
+                                                          const uint32_t* __restrict__ order, const int32_t* __restrict__ ext,
+                                                          const int64_t* __restrict__ tmp_off, const int32_t* __restrict__ list,
+                                                          const int32_t* __restrict__ count, int32_t* __restrict__ tmp_nbr,
+                                                          double* __restrict__ tmp_val, int32_t* __restrict__ cnt_out,
+                                                          unsigned long long* __restrict__ live_total, int32_t lcap, int32_t qcap) {
+    constexpr int NTB = NW * 64;
+    extern __shared__ Rec2 R_mw[];
+    Rec2* const R = R_mw;
+    uint16_t* const ulist = reinterpret_cast<uint16_t*>(R + lcap);
+    uint16_t* const dlist = ulist + (lcap + 2);
+    int32_t* const segq = reinterpret_cast<int32_t*>(dlist + (lcap + 2));   // (lcap is even: 4-byte aligned)
+    __shared__ uint32_t s_segmark[BIGCAP / 32 + 2];
+    __shared__ int32_t s_qcnt[2];
+    __shared__ int32_t s_seg_base[40], s_seg_first[40], s_seg_pref[41], s_nseg;   // the column as runs of slots in traversal order
+    __shared__ int32_t s_wtot[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt = lanemask_lt(lane);
+    const int32_t nbig = *count;
+    unsigned long long live_acc = 0ull;
+    for (int32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        const int32_t i = list[bi];
+        const int32_t v = (int32_t)order[i];
+        const int64_t toff = tmp_off[i];
+        if (tid == 0) {
+            // traversal order (:248-271): appended chunks newest first (each backwards), then the CSR segment backwards
+            const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
+            const int32_t acnt = A.vr[v].app_cnt;
+            int ns = 0, pref = 0;
+            int32_t idx = acnt - 1, base = A.vr[v].app_chunk;
+            int c = idx >= 0 ? chunk_of(idx) : 0;
+            while (idx >= 0) {
+                const int32_t cs = chunk_start(c);
+                s_seg_base[ns] = base + 1; s_seg_first[ns] = idx - cs;   // slot of traversal position 0 of this run = base + 1 + (idx - cs), then descending
+                s_seg_pref[ns] = pref; pref += idx - cs + 1; ++ns;
+                const int32_t prev = A.e[base].nbr;
+                idx = cs - 1; base = prev; --c;
+            }
+            s_seg_base[ns] = cp0; s_seg_first[ns] = cp1 - 1 - cp0; s_seg_pref[ns] = pref; pref += cp1 - cp0; ++ns;
+            s_seg_pref[ns] = pref;
+            s_nseg = ns;
+        }
+        __syncthreads();
+        const int32_t extv = s_seg_pref[s_nseg];
+        int32_t len0 = 0;
+        for (int32_t e0 = 0; e0 < extv; e0 += NTB) {
+            const int32_t e = e0 + tid;
+            double val = 0; int32_t nb = 0;
+            if (e < extv) {
+                int sgi = 0;
+                while (e >= s_seg_pref[sgi + 1]) ++sgi;
+                const int32_t sl = s_seg_base[sgi] + s_seg_first[sgi] - (e - s_seg_pref[sgi]);
+                const Slot g = A.e[sl]; val = g.val; nb = g.nbr;
+            }
+            const bool live = e < extv && val > 0;
+            const uint64_t mask = __ballot(live);
+            if (lane == 0) s_wtot[wave] = popc64(mask);
+            __syncthreads();
+            int32_t before = len0, tot = 0;
+            for (int w = 0; w < NW; ++w) { const int32_t t = s_wtot[w]; if (w < wave) before += t; tot += t; }
+            if (live) { Rec2 r; r.a = (double)nb; r.b = val; R[before + popc64(mask & lt)] = r; }
+            len0 += tot;
+            __syncthreads();
+        }
+        // sort by id (:314-315)
+        block_std_sort<Rec2, Rec2LessA, NW>(R, len0, Rec2LessA(), ulist, dlist, s_segmark, segq, s_qcnt, qcap);
+        // merge (:317-329), NTB positions at a time: heads by comparison with the predecessor, sums in sorted order; all reads of a
+        // block (its look-ahead included) come before its writes, which land at or below the block
+        int32_t m = 0;
+        for (int32_t p0 = 0; p0 < len0; p0 += NTB) {
+            const int32_t p = p0 + tid;
+            const bool act = p < len0;
+            Rec2 me = {0.0, 0.0};
+            double prev = -1.0;
+            if (act) { me = R[p]; if (p > 0) prev = R[p - 1].a; }
+            const bool head = act && me.a != prev;
+            if (head) for (int32_t q = p + 1; q < len0 && R[q].a == me.a; ++q) me.b += R[q].b;
+            const uint64_t mask = __ballot(head);
+            if (lane == 0) s_wtot[wave] = popc64(mask);
+            __syncthreads();
+            int32_t before = m, tot = 0;
+            for (int w = 0; w < NW; ++w) { const int32_t t = s_wtot[w]; if (w < wave) before += t; tot += t; }
+            if (head) R[before + popc64(mask & lt)] = me;
+            m += tot;
+            __syncthreads();
+        }
+        // order by o_n (:331-343)
+        if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) {
+            const int32_t gi = vgraph[v];
+            Rec2LessKeyed lk; lk.vbase = gd[gi].vbase; lk.kb = keyed_order_base(A.shuffle_seed + (uint64_t)gi, v - lk.vbase, 1);
+            block_std_sort<Rec2, Rec2LessKeyed, NW>(R, m, lk, ulist, dlist, s_segmark, segq, s_qcnt, qcap);
+        } else if (A.o_n == ON_ASC) block_std_sort<Rec2, Rec2LessB, NW>(R, m, Rec2LessB(), ulist, dlist, s_segmark, segq, s_qcnt, qcap);
+        else block_std_sort<Rec2, Rec2GreaterB, NW>(R, m, Rec2GreaterB(), ulist, dlist, s_segmark, segq, s_qcnt, qcap);
+        for (int32_t j = tid; j < m; j += NTB) { tmp_nbr[toff + j] = (int32_t)R[j].a; tmp_val[toff + j] = R[j].b; }
+        if (tid == 0) { cnt_out[i] = m; live_acc += (unsigned long long)len0; }
+        __syncthreads();
+    }
+    if (tid == 0 && live_acc) atomicAdd(&live_total[(blockIdx.x & (LIVE_SLOTS - 1)) * LIVE_STRIDE], live_acc);
 }
 
 __global__ __launch_bounds__(64) void k_sc_merge_huge(Arrays A, const GraphDesc* __restrict__ gd, const int32_t* __restrict__ vgraph,
