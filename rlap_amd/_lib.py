@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librlap_hip.so")
+LIB_PATH = os.environ.get("RLAP_AMD_LIB") or os.path.join(_HERE, "librlap_hip.so")   # (override: kernel-variant experiments)
 
 _lib = None
 
