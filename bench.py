@@ -317,7 +317,7 @@ def main():
             else:
                 import multiprocessing as mp
                 cores = min(_usable_cores(), 64)
-                sample = 2 * cores
+                sample = 8 * cores     # about 8 s of single-core work in all
                 with mp.get_context("fork").Pool(cores) as pool:
                     t1 = time.perf_counter()
                     per = pool.map(_c5_cpu_one, range(sample))
