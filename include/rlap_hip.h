@@ -83,6 +83,12 @@ int rlap_identity(rlap_handle h, const double* d_in, double* d_tmp, double* d_ou
  * (rlap/ops.py:47) into the COO arrays the calls below take. */
 int rlap_unpack_edge_info(rlap_handle h, const double* d_edge_info, int64_t E, int64_t* d_row, int64_t* d_col, double* d_w);
 
+/* Exchange format of sc_edge_info for the batched multi-GPU mode (no reference counterpart: the
+ * reference has no multi-process path): row [row, col, w] <-> two 64-bit words (row << 32 | col, bits of w), so
+ * that the RCCL all-gather moves 16 instead of 24 bytes per row.  d_packed holds 2 * rows 64-bit words.  Stream-ordered. */
+int rlap_pack_rows(rlap_handle h, const double* d_sc, int64_t rows, void* d_packed);
+int rlap_unpack_rows(rlap_handle h, const void* d_packed, int64_t rows, double* d_sc);
+
 /* The op.  Replaces ApproximateCholesky::setup + getSchurComplement
  * (factorizers.cc:46-73) for one graph:
  *   d_row/d_col/d_w : COO, E directed entries (d_w NULL = all ones; w==0 rows are

@@ -16,7 +16,7 @@ EXPORTS = [
     "rlap_create", "rlap_destroy", "rlap_set_stream", "rlap_set_timing", "rlap_status_string",
     "rlap_identity", "rlap_unpack_edge_info", "rlap_approx_chol", "rlap_approx_chol_batched",
     "rlap_rng_uniforms", "rlap_util_ba_graph", "rlap_debug_wave_sort",
-    "rlap_approx_chol_from_edges", "rlap_debug_set_limits",
+    "rlap_approx_chol_from_edges", "rlap_debug_set_limits", "rlap_pack_rows", "rlap_unpack_rows",
 ]
 
 
@@ -70,6 +70,10 @@ def load():
                                                 ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(Stats)]
     lib.rlap_debug_set_limits.restype = ci
     lib.rlap_debug_set_limits.argtypes = [vp, ctypes.c_double, ctypes.c_double, i64, i64]
+    lib.rlap_pack_rows.restype = ci
+    lib.rlap_pack_rows.argtypes = [vp, vp, i64, vp]
+    lib.rlap_unpack_rows.restype = ci
+    lib.rlap_unpack_rows.argtypes = [vp, vp, i64, vp]
     lib.rlap_rng_uniforms.restype = ci
     lib.rlap_rng_uniforms.argtypes = [vp, i64, vp]
     lib.rlap_debug_wave_sort.restype = ci

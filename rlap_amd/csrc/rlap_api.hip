@@ -586,6 +586,24 @@ int rlap_unpack_edge_info(rlap_handle h, const double* d_edge_info, int64_t E, i
     return RLAP_OK;
 }
 
+int rlap_pack_rows(rlap_handle h, const double* d_sc, int64_t rows, void* d_packed) {
+    if (!h || rows < 0) return RLAP_E_BAD_ARG;
+    if (rows == 0) return RLAP_OK;
+    DeviceGuard dg(h->device);
+    hipLaunchKernelGGL(k_pack_rows, dim3(nblk(rows, 256)), dim3(256), 0, h->stream, d_sc, rows, reinterpret_cast<unsigned long long*>(d_packed));
+    HIPCHK(hipGetLastError());
+    return RLAP_OK;
+}
+
+int rlap_unpack_rows(rlap_handle h, const void* d_packed, int64_t rows, double* d_sc) {
+    if (!h || rows < 0) return RLAP_E_BAD_ARG;
+    if (rows == 0) return RLAP_OK;
+    DeviceGuard dg(h->device);
+    hipLaunchKernelGGL(k_unpack_rows, dim3(nblk(rows, 256)), dim3(256), 0, h->stream, reinterpret_cast<const unsigned long long*>(d_packed), rows, d_sc);
+    HIPCHK(hipGetLastError());
+    return RLAP_OK;
+}
+
 int rlap_approx_chol_batched(rlap_handle h, const int64_t* d_row, const int64_t* d_col, const double* d_w, int64_t E, int64_t G,
                              const int64_t* h_node_ptr, const int64_t* h_num_remove, int o_v, int o_n, const int64_t* d_perm,
                              uint64_t shuffle_seed, double* d_out, int64_t out_cap_rows, int64_t* h_out_row_ptr, rlap_stats* h_stats) {

@@ -78,6 +78,8 @@ struct ScScratch {
 
 __global__ void k_mt19937_64_table(double* out, int64_t count);
 __global__ void k_transpose_copy(const double* in, double* out, int64_t rows, int64_t cols, int to_colmajor);
+__global__ void k_pack_rows(const double* sc, int64_t m, unsigned long long* packed);
+__global__ void k_unpack_rows(const unsigned long long* packed, int64_t m, double* sc);
 __global__ void k_unpack_edge_info(const double* ei, int64_t E, int64_t* row, int64_t* col, double* w);
 __global__ void k_vertex_graph(const int64_t* node_ptr, int G, int32_t* vgraph, int64_t N);
 __global__ void k_edge_keys(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t N, const int32_t* vgraph,

@@ -98,6 +98,24 @@ __global__ void k_unpack_edge_info(const double* __restrict__ ei, int64_t E, int
     w[p] = ei[3 * p + 2];
 }
 
+// Exchange format of sc_edge_info between GPUs (the RCCL all-gather): a row [row, col, w] as two 64-bit
+// words -- (row << 32 | col), the bits of w -- 16 bytes over xGMI instead of 24.  One thread per row, both directions.
+__global__ void k_pack_rows(const double* __restrict__ sc, int64_t m, unsigned long long* __restrict__ packed) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const unsigned long long r = (unsigned long long)(long long)sc[3 * p], c = (unsigned long long)(long long)sc[3 * p + 1];
+    packed[2 * p] = (r << 32) | (c & 0xFFFFFFFFull);
+    packed[2 * p + 1] = (unsigned long long)__double_as_longlong(sc[3 * p + 2]);
+}
+__global__ void k_unpack_rows(const unsigned long long* __restrict__ packed, int64_t m, double* __restrict__ sc) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= m) return;
+    const unsigned long long ids = packed[2 * p];
+    sc[3 * p] = (double)(ids >> 32);
+    sc[3 * p + 1] = (double)(ids & 0xFFFFFFFFull);
+    sc[3 * p + 2] = __longlong_as_double((long long)packed[2 * p + 1]);
+}
+
 // ---------------------------------------------------------------------------
 // K1: COO -> CSR
 // ---------------------------------------------------------------------------

@@ -47,17 +47,43 @@ def all_gather_rows(local: torch.Tensor, group=None) -> Tuple[torch.Tensor, torc
     return out, counts_h
 
 
-def all_gather_edge_rows(sc: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-gather of (m_r, 3) f64 [row, col, w] blocks with the two node ids packed into one 64-bit word for the
-    exchange: 16 bytes per row over xGMI instead of 24.  Returns the same (cat, counts) as all_gather_rows."""
+def _pack_rows(sc: torch.Tensor) -> torch.Tensor:
+    """(m,3) f64 [row, col, w] -> (m,2) int64 [(row << 32 | col), bits of w]; one HIP kernel on the GPU, torch ops on the CPU."""
+    if sc.is_cuda:
+        from . import ops
+        sc = sc.contiguous()
+        packed = torch.empty((sc.shape[0], 2), dtype=torch.int64, device=sc.device)
+        lib, h = ops._handle(sc.device)
+        rc = lib.rlap_pack_rows(h, sc.data_ptr(), sc.shape[0], packed.data_ptr())
+        if rc != 0:
+            ops._raise(rc)
+        return packed
     ids = (sc[:, 0].to(torch.int64) << 32) | sc[:, 1].to(torch.int64)
-    packed = torch.stack([ids, sc[:, 2].contiguous().view(torch.int64)], dim=1)
-    allp, counts = all_gather_rows(packed, group=group)
-    out = torch.empty((allp.shape[0], 3), dtype=torch.float64, device=sc.device)
+    return torch.stack([ids, sc[:, 2].contiguous().view(torch.int64)], dim=1)
+
+
+def _unpack_rows(allp: torch.Tensor) -> torch.Tensor:
+    if allp.is_cuda:
+        from . import ops
+        allp = allp.contiguous()
+        out = torch.empty((allp.shape[0], 3), dtype=torch.float64, device=allp.device)
+        lib, h = ops._handle(allp.device)
+        rc = lib.rlap_unpack_rows(h, allp.data_ptr(), allp.shape[0], out.data_ptr())
+        if rc != 0:
+            ops._raise(rc)
+        return out
+    out = torch.empty((allp.shape[0], 3), dtype=torch.float64, device=allp.device)
     out[:, 0] = (allp[:, 0] >> 32).to(torch.float64)
     out[:, 1] = (allp[:, 0] & 0xFFFFFFFF).to(torch.float64)
     out[:, 2] = allp[:, 1].contiguous().view(torch.float64)
-    return out, counts
+    return out
+
+
+def all_gather_edge_rows(sc: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather of (m_r, 3) f64 [row, col, w] blocks with the two node ids packed into one 64-bit word for the
+    exchange: 16 bytes per row over xGMI instead of 24.  Returns the same (cat, counts) as all_gather_rows."""
+    allp, counts = all_gather_rows(_pack_rows(sc), group=group)
+    return _unpack_rows(allp), counts
 
 
 def sharded_approximate_cholesky(

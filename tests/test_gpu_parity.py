@@ -692,3 +692,19 @@ def test_real_datasets_if_present(ops, env, o_v):
     ref = oracle.approximate_cholesky(und, None, n, n // 2, o_v, "asc", perm=perm, shuffle_seed=3)
     got = gpu_call(ops, und, None, n, n // 2, o_v, "asc", perm=perm, seed=3)
     assert_same(got, ref, f"{env} {o_v}/asc")
+
+
+def test_exchange_format_pack_unpack(ops):
+    """The 16-byte exchange rows of the multi-GPU all-gather (rlap_pack_rows / rlap_unpack_rows): bit-identical to the torch
+    formulation the CPU (gloo) tests use, and a lossless round trip."""
+    from rlap_amd import distributed as D
+    rs = np.random.RandomState(4)
+    m = 100_003
+    sc = torch.from_numpy(np.stack([rs.randint(0, 1 << 30, m).astype(np.float64), rs.randint(0, 1 << 30, m).astype(np.float64),
+                                    rs.rand(m) * 3 + 1e-9], axis=1))
+    p_cpu = D._pack_rows(sc)
+    p_gpu = D._pack_rows(sc.cuda())
+    assert p_gpu.is_cuda and torch.equal(p_gpu.cpu(), p_cpu)
+    back = D._unpack_rows(p_gpu)
+    assert torch.equal(back.cpu(), sc) and torch.equal(D._unpack_rows(p_cpu), sc)
+    assert D._pack_rows(sc[:0].cuda()).shape == (0, 2)
