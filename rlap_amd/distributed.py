@@ -129,7 +129,8 @@ def sharded_approximate_cholesky(
         sc, row_ptr = compute_fn(ei, w, node_ptr, list(num_remove[lo:hi]), o_v, o_n, seed + lo)
         # back to per-graph local ids
         if sc.shape[0]:
-            gid = torch.bucketize(torch.arange(sc.shape[0]), row_ptr[1:].cpu(), right=True).to(sc.device)
+            # (on the device the rows live on: no host-side pass over the rows)
+            gid = torch.bucketize(torch.arange(sc.shape[0], device=sc.device), row_ptr[1:].to(sc.device), right=True)
             off = node_ptr.to(sc.device)[gid].to(sc.dtype)
             sc = sc.clone()
             sc[:, 0] -= off
