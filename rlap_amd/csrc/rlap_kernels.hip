@@ -2969,7 +2969,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_t(Arrays A, const GraphDesc* __
         const int32_t v = (int32_t)order[i];
         const int64_t toff = tmp_off[i];
         const int32_t ex = ext[i];
-        if (ex > SCAP) {
+        if (CAP == SCAP && ex > SCAP) {   // (only the last tier's list can hold such a column: the other instantiations stay lean)
             // long column: k_sc_merge_big / k_sc_merge_huge take it, unless it is too long even for their 16-bit stop lists:
             // then the sequential form in global scratch (one lane)
             if (lane == 0 && ex > HUGECAP) {
