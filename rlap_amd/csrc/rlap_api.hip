@@ -308,8 +308,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         ENSURE(h->sorttmp, bytes);
         bytes = h->sorttmp.cap;
         HIPCHK(rocprim::radix_sort_pairs(h->sorttmp.p, bytes, h->idx0.as<uint32_t>(), skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
-        hipLaunchKernelGGL(k_twin_sorted, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(),
-                           h->slot_col.as<int32_t>(), h->idx0.as<int32_t>(), T, nnz_p, acc);
+        hipLaunchKernelGGL(k_twin_sorted, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(), T, nnz_p, acc);
+        hipLaunchKernelGGL(k_twin_store, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(), T, nnz_p);
     }
     HIPCHK(hipMemcpyAsync(h->pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
     // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)

@@ -268,7 +268,7 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
     // duplicates summed in input order (setFromTriplets); unweighted symmetrised input is an edge SET (PyG coalesce): weight 1
     if (!set_semantics) for (int64_t q = i + 1; q < E && keys[q] == k; ++q) sum += w ? w[idx[q]] : 1.0;
     int32_t c = (int32_t)(k >> kbits);
-    Slot g; g.val = sum; g.nbr = (int32_t)(k & ((1ull << kbits) - 1ull)); g.twin = -1;
+    Slot g; g.val = sum; g.nbr = (int32_t)(k & ((1ull << kbits) - 1ull)); g.twin = c;   // (twin holds the COLUMN until k_twin_store: k_twin_sorted reads a partner's ids and weight with one 16-byte load)
     ent[s] = g;
     slot_col[s] = c;
     nbr32[s] = g.nbr;   // dense copy of the row ids: key of the sort that finds the twins (k_twin_sorted)
@@ -295,25 +295,22 @@ __global__ void k_colptr(const int32_t* __restrict__ slot_col, const int32_t* __
 // pattern that pair is the transpose of the k-th smallest (col, row) pair, i.e. of slot k: twin[k] = T[k].  Any slot whose
 // partner does not hold the transposed ids proves the pattern asymmetric.  (One radix sort of 4-byte keys over bits_for(N)
 // bits and two gathers per entry instead of log2(degree) dependent probes.)
-__global__ __launch_bounds__(256) void k_twin_sorted(Slot* __restrict__ ent, const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nbr32,
-                                                     const uint32_t* __restrict__ T, const int32_t* __restrict__ nnz_p, double* __restrict__ acc) {
+__global__ __launch_bounds__(256) void k_twin_sorted(const Slot* __restrict__ ent, const uint32_t* __restrict__ T, const int32_t* __restrict__ nnz_p,
+                                                     double* __restrict__ acc) {
     const int32_t nnz = *nnz_p;
     double d2 = 0, n2 = 0;
     bool asym = false;
     for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += gridDim.x * blockDim.x) {
-        const int32_t c = slot_col[p], r = nbr32[p];
-        const double v = ent[p].val;
-        n2 += v * v;
+        const Slot me = ent[p];                  // (val, row, column)
+        n2 += me.val * me.val;
         const uint32_t q = T[p];
-        if (q < (uint32_t)nnz && nbr32[q] == c && slot_col[q] == r) {
-            ent[p].twin = (int32_t)q;
-            const double d = v - ent[q].val;
-            d2 += d * d;
-        } else {
-            ent[p].twin = -1;
-            d2 += 2 * v * v;
-            asym = true;
+        bool ok = q < (uint32_t)nnz;
+        if (ok) {
+            const Slot tw = ent[q];              // one 16-byte gather: the partner's weight, row and column
+            ok = tw.nbr == me.twin && tw.twin == me.nbr;
+            if (ok) { const double d = me.val - tw.val; d2 += d * d; }
         }
+        if (!ok) { d2 += 2 * me.val * me.val; asym = true; }
     }
     if (asym) acc[2] = 1.0;  // structurally asymmetric
     for (int off = 32; off > 0; off >>= 1) { d2 += __shfl_down(d2, off); n2 += __shfl_down(n2, off); }
@@ -326,6 +323,11 @@ __global__ __launch_bounds__(256) void k_twin_sorted(Slot* __restrict__ ent, con
         if (bd != 0.0) atomicAdd(&acc[0], bd);
         if (bn != 0.0) atomicAdd(&acc[1], bn);
     }
+}
+// ... and the twin indices stored once every partner has been read (the field held the column until now)
+__global__ void k_twin_store(Slot* __restrict__ ent, const uint32_t* __restrict__ T, const int32_t* __restrict__ nnz_p) {
+    const int32_t nnz = *nnz_p;
+    for (int32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += gridDim.x * blockDim.x) ent[p].twin = (int32_t)T[p];
 }
 
 // ---------------------------------------------------------------------------
