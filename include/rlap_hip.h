@@ -12,7 +12,8 @@
  * All work is enqueued on the handle's HIP stream without any host synchronisation
  * in between (every workspace size is an upper bound computed from E, n and G; input
  * checks and growth limits are evaluated by the kernels); the call returns after ONE
- * read-back of the scalars it reports.
+ * read-back of the scalars it reports. (Inputs of >= 2^21 entries: one more, early, 32-byte read-back
+ * decides whether the COO sort can be skipped because the input is sorted already.)
  * Threading: a handle owns its workspace and serialises the calls made on it (a mutex);
  * for concurrent calls give every host thread its own handle (and stream) -- the
  * reference builds a fresh ApproximateCholesky per call (py_api_binder.cc:57).
@@ -61,7 +62,7 @@ typedef struct {
     float ms_sc_compact;  /* output pass B alone (ballot/prefix compaction)   */
     float ms_total;
     int32_t n_retries;    /* times the call was repeated with a larger workspace (RLAP_E_*_OVERFLOW inside) */
-    int32_t reserved;
+    int32_t reserved;     /* COO sort: 0 done, 1 skipped (input in (col,row) order), 2 skipped, input in (row,col) order read transposed */
     int64_t n_rounds;     /* elimination: batch rounds, summed over graphs              */
     int64_t n_singles;    /* elimination: vertices that took the single-vertex path     */
 } rlap_stats;

@@ -75,6 +75,7 @@ struct rlap_handle_s {
     // test hooks (rlap_debug_set_limits): tiny first sizes so that the retry path runs
     double dbg_pool = -1.0, dbg_log = -1.0; int64_t dbg_rng = -1, dbg_scr = -1;
     int64_t total_retries = 0;
+    bool force_sort = false;      // the next attempt sorts the COO whatever order it is in (set when a skipped sort cannot be trusted)
 };
 
 namespace {
@@ -119,6 +120,8 @@ int excl_scan(rlap_handle h, In* in, Out* out, int64_t n) {
     HIPCHK(rocprim::exclusive_scan(h->sorttmp.p, bytes, in, out, (Out)0, (size_t)n, rocprim::plus<Out>(), h->stream));
     return RLAP_OK;
 }
+
+constexpr int64_t SORT_SKIP_MIN = 1 << 21;   // directed entries from which the order of the input is looked at before sorting it
 
 inline unsigned bits_for(uint64_t maxval) { unsigned b = 1; while (b < 64 && (maxval >> b) != 0) ++b; return b; }
 
@@ -281,21 +284,48 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     if (G > 1) hipLaunchKernelGGL(k_vertex_graph, dim3(nblk(N, 256)), dim3(256), 0, s, h->node_ptr_d.as<int64_t>(), (int)G, h->vgraph.as<int32_t>(), N);
 
     const int kbits = (int)bits_for((uint64_t)(N > 1 ? N - 1 : 1));
+    bool swapped = false;   // the input was in (row, col) order and is read transposed (same matrix when it is exactly symmetric)
+    uint64_t* keys_sorted = h->keys1.as<uint64_t>();
+    uint32_t* idx_sorted = h->idx1.as<uint32_t>();
+    uint32_t* rowid = h->idx0.as<uint32_t>();   // dense row ids of the slots (key of the twin sort); a buffer the COO sort has left free
     if (Eeff > 0) {
         hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_row, c.d_col, c.d_w, E, N, G > 1 ? h->vgraph.as<int32_t>() : (const int32_t*)nullptr,
                            c.symmetrize, kbits, h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), flags);
-        // keys are (col << kbits | row) with ids < N, or all ones for dropped entries (bit 2 * kbits makes these sort last)
-        int rc = sort_pairs(h, h->keys0.as<uint64_t>(), h->keys1.as<uint64_t>(), h->idx0.as<uint32_t>(), h->idx1.as<uint32_t>(), Eeff, 0,
-                            (unsigned)std::min(64, 2 * kbits + 1));
-        if (rc) return rc;
-        { Fills F2; F2.add(h->idx0.p, Eeff, (int32_t)N); F2.launch(s); }   // idx0 becomes the dense row-id array: slots beyond nnz hold N (sorts last)
-        hipLaunchKernelGGL(k_heads, dim3(nblk(Eeff + 1, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), Eeff, h->head.as<int32_t>());
-        rc = excl_scan(h, h->head.as<int32_t>(), h->pos.as<int32_t>(), Eeff + 1);
+        // Large inputs: one early look at the order flags (the call's only other host synchronisation) -- a COO that is sorted by
+        // (col, row) needs no sort, one sorted by (row, col) (PyG coalesce) is read transposed and needs none either; exact symmetry,
+        // which makes the transposed reading the same matrix, is verified with the twins (else the call is repeated with the sort).
+        bool skip_sort = false;
+        int64_t skip_min = SORT_SKIP_MIN;
+        if (const char* e = std::getenv("RLAP_SORT_SKIP_MIN")) skip_min = std::atoll(e);   // (tests: exercise the order check on small inputs)
+        if (Eeff >= skip_min && !c.symmetrize && !h->force_sort) {
+            int32_t fl[FLAG_COUNT];
+            HIPCHK(hipMemcpyAsync(fl, flags, sizeof(fl), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (!fl[FLAG_UNSORTED_CR]) skip_sort = true;
+            else if (!fl[FLAG_UNSORTED_RC] && !fl[FLAG_RANGE]) {
+                hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_col, c.d_row, c.d_w, E, N, G > 1 ? h->vgraph.as<int32_t>() : (const int32_t*)nullptr,
+                                   0, kbits, h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), flags);
+                skip_sort = true; swapped = true;
+            }
+        }
+        st.reserved = skip_sort ? (swapped ? 2 : 1) : 0;
+        if (skip_sort) {
+            keys_sorted = h->keys0.as<uint64_t>(); idx_sorted = h->idx0.as<uint32_t>();
+            rowid = h->idx1.as<uint32_t>();
+        } else {
+            // keys are (col << kbits | row) with ids < N, or all ones for dropped entries (bit 2 * kbits makes these sort last)
+            int rc = sort_pairs(h, h->keys0.as<uint64_t>(), h->keys1.as<uint64_t>(), h->idx0.as<uint32_t>(), h->idx1.as<uint32_t>(), Eeff, 0,
+                                (unsigned)std::min(64, 2 * kbits + 1));
+            if (rc) return rc;
+        }
+        { Fills F2; F2.add(rowid, Eeff, (int32_t)N); F2.launch(s); }   // dense row-id array: slots beyond nnz hold N (sorts last)
+        hipLaunchKernelGGL(k_heads, dim3(nblk(Eeff + 1, 256)), dim3(256), 0, s, keys_sorted, Eeff, h->head.as<int32_t>());
+        int rc = excl_scan(h, h->head.as<int32_t>(), h->pos.as<int32_t>(), Eeff + 1);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(nnz_p, h->pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, h->keys1.as<uint64_t>(), h->idx1.as<uint32_t>(), h->head.as<int32_t>(),
+        hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, keys_sorted, idx_sorted, h->head.as<int32_t>(),
                            h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, kbits, h->ent.as<Slot>(), h->slot_col.as<int32_t>(),
-                           h->idx0.as<int32_t>());   // (idx0 is free once the sort has run: dense neighbour ids for the twin search)
+                           reinterpret_cast<int32_t*>(rowid));
     }
     hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, h->slot_col.as<int32_t>(), nnz_p, (int32_t)N, h->colptr.as<int32_t>());
     if (Eeff > 0) {
@@ -304,10 +334,10 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         uint32_t* T = skeys + Eeff;
         size_t bytes = 0;
         rocprim::counting_iterator<uint32_t> iota(0u);
-        HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->idx0.as<uint32_t>(), skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, rowid, skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
         ENSURE(h->sorttmp, bytes);
         bytes = h->sorttmp.cap;
-        HIPCHK(rocprim::radix_sort_pairs(h->sorttmp.p, bytes, h->idx0.as<uint32_t>(), skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
+        HIPCHK(rocprim::radix_sort_pairs(h->sorttmp.p, bytes, rowid, skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
         hipLaunchKernelGGL(k_twin_sorted, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(), T, nnz_p, acc);
         hipLaunchKernelGGL(k_twin_store, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(), T, nnz_p);
     }
@@ -472,6 +502,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         return R.status;
     }
     if (R.flags[FLAG_SCR]) { *retry_kind = 4; *retry_need = R.scr_need; return RLAP_E_INTERNAL; }
+    if (swapped && R.acc[0] != 0.0) { *retry_kind = 5; return RLAP_E_INTERNAL; }   // symmetric only within the tolerance: repeat, reading the input as given
     for (int64_t g = 0; g <= G; ++g) c.h_out_row_ptr[g] = out_ptr_h[g];
     if (R.m_total > c.out_cap) { c.h_out_row_ptr[G] = R.m_total; return RLAP_E_OUT_OVERFLOW; }
     return RLAP_OK;
@@ -498,7 +529,9 @@ int run_call(rlap_handle h, const Call& c) {
         else if (kind == 2) { if (h->dbg_log >= 0) h->dbg_log = -1.0; else h->log_factor *= 2; }
         else if (kind == 3) { if (h->dbg_rng >= 0) h->dbg_rng = -1; else h->rng_min = std::max<int64_t>(2 * h->rng_len, 1 << 16); }
         else if (kind == 4) { if (h->dbg_scr >= 0) h->dbg_scr = -1; h->scr_budget = std::max<int64_t>(h->scr_budget, need + 8); }
+        else if (kind == 5) h->force_sort = true;
     }
+    h->force_sort = false;
     h->total_retries += retries;
     if (c.st) c.st->n_retries = retries;
     return rc;

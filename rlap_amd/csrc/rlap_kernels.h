@@ -7,7 +7,7 @@
 
 namespace rlap {
 
-enum { FLAG_RANGE = 0, FLAG_CROSS = 1, FLAG_PERM = 2, FLAG_SCR = 3, FLAG_COUNT = 4 };
+enum { FLAG_RANGE = 0, FLAG_CROSS = 1, FLAG_PERM = 2, FLAG_SCR = 3, FLAG_UNSORTED_CR = 4, FLAG_UNSORTED_RC = 5, FLAG_COUNT = 8 };
 
 // several (pointer, count, value) fills done by one launch
 struct FillJobs { int32_t* ptr[16]; int64_t count[16]; int32_t value[16]; int n; };

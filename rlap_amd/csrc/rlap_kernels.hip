@@ -151,6 +151,15 @@ __global__ void k_edge_keys(const int64_t* __restrict__ row, const int64_t* __re
     }
     keys[p] = k;
     idx[p] = (uint32_t)q;
+    // is the input in (col, row) order already -- or in (row, col) order, what PyG's coalesce leaves?  (Then the radix sort
+    // can be skipped, rlap_api.hip.)  Every entry is compared with its predecessor in both orders.
+    if (!symmetrize && p > 0) {
+        const int64_t r0 = row[p - 1], c0 = col[p - 1];
+        const double w0 = w ? w[p - 1] : 1.0;
+        const bool bad = (k == ~0ull) || w0 == 0 || r0 < 0 || r0 >= N || c0 < 0 || c0 >= N;
+        if (bad || (((uint64_t)c0 << kbits) | (uint64_t)r0) > k) flags[FLAG_UNSORTED_CR] = 1;
+        if (bad || (((uint64_t)r0 << kbits) | (uint64_t)c0) > (((uint64_t)r << kbits) | (uint64_t)c)) flags[FLAG_UNSORTED_RC] = 1;
+    } else if (p == 0 && k == ~0ull) { flags[FLAG_UNSORTED_CR] = 1; flags[FLAG_UNSORTED_RC] = 1; }
 }
 
 // num_nodes = edge_index.max() + 1 (scripts/augmentor_benchmarks.py:77) without a torch reduction + .item()

@@ -708,3 +708,50 @@ def test_exchange_format_pack_unpack(ops):
     back = D._unpack_rows(p_gpu)
     assert torch.equal(back.cpu(), sc) and torch.equal(D._unpack_rows(p_cpu), sc)
     assert D._pack_rows(sc[:0].cuda()).shape == (0, 2)
+
+
+def test_sorted_input_skips_the_coo_sort(ops, monkeypatch):
+    """Large inputs are looked at before they are sorted: a COO in (col,row) order needs no sort, one in (row,col) order (PyG
+    coalesce) is read transposed -- the same matrix when it is exactly symmetric, which the twin check verifies; else the call
+    repeats itself with the sort.  RLAP_SORT_SKIP_MIN lowers the size threshold so that small graphs take these paths."""
+    monkeypatch.setenv("RLAP_SORT_SKIP_MIN", "1")
+    n = 3000
+    ei = ba_graph(n, 6, 9)                       # sorted by (col, row)
+    rc_order = np.lexsort((ei[1], ei[0]))        # the same entries sorted by (row, col)
+    ei_rc = ei[:, rc_order]
+    shuffled = ei[:, np.random.RandomState(1).permutation(ei.shape[1])]
+    w = sym_weights(ei, n, 3)
+    for o_v, o_n in (("degree", "asc"), ("coarsen", "asc"), ("degree", "random")):
+        for wts in (None, w):
+            ref = oracle.approximate_cholesky(ei, wts, n, n // 2, o_v, o_n, shuffle_seed=4)
+            got = gpu_call(ops, ei, wts, n, n // 2, o_v, o_n, seed=4)
+            assert ops.last_stats["reserved"] == 1 and ops.last_stats["n_retries"] == 0
+            assert_same(got, ref, f"(col,row)-sorted {o_v}/{o_n}")
+            got = gpu_call(ops, ei_rc, None if wts is None else wts[rc_order], n, n // 2, o_v, o_n, seed=4)
+            assert ops.last_stats["reserved"] == 2 and ops.last_stats["n_retries"] == 0
+            assert_same(got, ref, f"(row,col)-sorted {o_v}/{o_n}")
+            got = gpu_call(ops, shuffled, None, n, n // 2, o_v, o_n, seed=4) if wts is None else got
+            if wts is None:
+                assert ops.last_stats["reserved"] == 0
+                assert_same(got, ref, f"shuffled {o_v}/{o_n}")
+    # (row,col)-sorted input whose two directions differ in the last bits (inside isApprox's tolerance): the transposed reading
+    # would swap them -- the call notices and repeats itself reading the input as given
+    w2 = w.copy()
+    upper = ei[0] < ei[1]
+    w2[upper] = w2[upper] * (1 + 2e-16)
+    ref = oracle.approximate_cholesky(ei_rc, w2[rc_order], n, n // 2, "degree", "asc")
+    got = gpu_call(ops, ei_rc, w2[rc_order], n, n // 2, "degree", "asc")
+    assert ops.last_stats["n_retries"] == 1 and ops.last_stats["reserved"] == 0
+    assert_same(got, ref, "almost symmetric, (row,col)-sorted")
+    # duplicates in sorted input are summed in input order as before
+    eid = np.concatenate([ei, ei[:, :50]], axis=1)
+    eid = eid[:, np.lexsort((eid[0], eid[1]))]
+    wd = np.ones(eid.shape[1])
+    # (duplicating one direction only makes the matrix asymmetric: duplicate both directions of the first 25 undirected edges)
+    a, b = ei[0, :25], ei[1, :25]
+    eid = np.concatenate([ei, np.stack([a, b]), np.stack([b, a])], axis=1)
+    eid = eid[:, np.lexsort((eid[0], eid[1]))]
+    ref = oracle.approximate_cholesky(eid, None, n, n // 2, "degree", "asc")
+    got = gpu_call(ops, eid, None, n, n // 2, "degree", "asc")
+    assert ops.last_stats["reserved"] == 1
+    assert_same(got, ref, "sorted input with duplicates")
