@@ -62,6 +62,8 @@ struct rlap_handle_s {
     DevBuf skey0, skey1, sval0, sval1;
     DevBuf rng;
     int64_t rng_len = 0;
+    DevBuf eqtab;   // k_eq_tables, built with the first call
+    bool eqtab_built = false;
     DevBuf scr_rec, scr_i32, scr_f64;
     // output
     DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, biglist, biglists, hugelists, results;
@@ -391,6 +393,13 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     A.perm = d_perm; A.o_v = c.o_v; A.o_n = c.o_n; A.shuffle_seed = c.seed;
     ElimScratch ES;
     ES.rec = h->scr_rec.as<SRec>(); ES.i32 = h->scr_i32.as<int32_t>(); ES.f64 = h->scr_f64.as<double>(); ES.cap = scr_total;
+    if (!h->eqtab_built) {
+        ENSURE(h->eqtab, EQTAB_BYTES);
+        launch_eq_tables(s, h->eqtab.as<uint8_t>());
+        HIPCHK(hipGetLastError());
+        h->eqtab_built = true;
+    }
+    ES.eqtab = h->eqtab.as<uint8_t>();
     ES.prof = nullptr;
     const char* prof_env = std::getenv("RLAP_PHASE_PROFILE");   // diagnostic only: per-phase clock sums of graph 0
     if (prof_env && prof_env[0] == '1') {
@@ -560,7 +569,7 @@ int rlap_destroy(rlap_handle h) {
     DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->scal, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
                       &h->deg, &h->colptr, &h->slot_col, &h->permchk, &h->genperm, &h->ent, &h->vrec,
                       &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
-                      &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
+                      &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->eqtab, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
                       &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->biglist, &h->biglists, &h->hugelists, &h->results};
     DeviceGuard dg(h->device);
     if (h->h_results) (void)hipHostFree(h->h_results);

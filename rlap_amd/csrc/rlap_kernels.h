@@ -22,6 +22,9 @@ struct CallResults {
     int32_t pool_used, log_used;
 };
 constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
+constexpr int ECAP_SMALL = 320;   // the same for the 256-thread shape (four workgroups per CU: 40 KB of LDS each)
+constexpr int EQTAB_OFF32 = 2 * 48 * 64;                 // equal-key permutation tables: 64-slot candidates first (perm, inverse), then 32-slot
+constexpr int EQTAB_BYTES = EQTAB_OFF32 + 2 * 16 * 32;
 constexpr int SCAP = 512;  // output pass: same
 constexpr int BIGCAP = 7168;  // output pass, long columns: one workgroup, 125 KB LDS record array + 31 KB LDS stop lists of the sort
 constexpr int BIG_LDS_BYTES = BIGCAP * 16 + 2 * (BIGCAP + 2) * 2;
@@ -45,6 +48,7 @@ struct ElimScratch {
     int32_t* i32;   // 10 arrays of `cap` ints, interleaved per array
     double* f64;    // 4 arrays of `cap` doubles
     int64_t cap;    // total entries over all graphs
+    const uint8_t* eqtab;   // k_eq_tables (per handle)
     long long* prof; // optional diagnostic build only: per-phase cycle sums of graph 0 (nullptr in production)
     __host__ __device__ ColBuf colbuf(int64_t base) const {
         ColBuf B;
@@ -100,6 +104,7 @@ __global__ void k_colptr(const int32_t* slot_col, const int32_t* nnz_p, int32_t 
 __global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, VRec* vr, uint64_t* skey, uint32_t* sval);
 __global__ void k_bucket_bounds(const uint32_t* order, const VRec* vr, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
                                 int32_t* ocur, int32_t* oend, int32_t* origpos);
+void launch_eq_tables(hipStream_t stream, uint8_t* out);
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
                             int32_t* batch_pos, const int32_t* flags, const double* acc);
 __global__ void k_sc_keys(const VRec* vr, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,

@@ -808,23 +808,24 @@ struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) co
 struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
 
 
-struct ElimLds {
-    SRec rec[ECAP];  // sort records; after ordering re-used as cum[ECAP] + newv[ECAP]
-    double a_val[ECAP];
-    double b_val[ECAP];
-    int32_t a_slot[ECAP], a_nbr[ECAP], a_twin[ECAP];
-    int32_t b_slot[ECAP], b_nbr[ECAP], b_twin[ECAP], b_pos[ECAP], b_dup[ECAP];
-    int32_t ksel[ECAP], t_key[ECAP], t_mv[ECAP], t_of[ECAP], t_cnt[ECAP], t_chunk[ECAP], t_list[ECAP], t_rank[ECAP], pslot[ECAP];
-    WaveSortScratchT<ECAP> ws;
-    alignas(16) double skey[ECAP + 8];   // sort keys, contiguous (rank sort reads them 8 at a time)
+template <int EC>
+struct ElimLdsT {
+    SRec rec[EC];  // sort records; after ordering re-used as cum[EC] + newv[EC]
+    double a_val[EC];
+    double b_val[EC];
+    int32_t a_slot[EC], a_nbr[EC], a_twin[EC];
+    int32_t b_slot[EC], b_nbr[EC], b_twin[EC], b_pos[EC], b_dup[EC];
+    int32_t ksel[EC], t_key[EC], t_mv[EC], t_of[EC], t_cnt[EC], t_chunk[EC], t_list[EC], t_rank[EC], pslot[EC];
+    WaveSortScratchT<EC> ws;
+    alignas(16) double skey[EC + 8];   // sort keys, contiguous (rank sort reads them 8 at a time)
 };
 
 // Rank sort == any stable sort. Exact w.r.t. std::sort when cnt <= 16 (pure
 // insertion sort, stable) or when all keys are distinct (unique answer).
 // Returns true if it wrote rec[rank] = {key, idx}; false if ties need the
 // sequential emulation.
-template <bool GREATER>
-__device__ __forceinline__ bool wave_rank_sort(ElimLds& L, int cnt, int lane) {   // keys staged in L.skey[0..cnt)
+template <bool GREATER, int EC>
+__device__ __forceinline__ bool wave_rank_sort(ElimLdsT<EC>& L, int cnt, int lane) {   // keys staged in L.skey[0..cnt)
     // only this wave is running (the others wait at a barrier): LDS latency is exposed, so the keys are read
     // eight at a time before they are compared.  NaN padding compares false with everything.
     const int cpad = (cnt + 7) & ~7;
@@ -861,8 +862,8 @@ __device__ __forceinline__ bool wave_rank_sort(ElimLds& L, int cnt, int lane) { 
 
 // std::sort order of the staged keys L.skey[0..cnt) into L.rec[] = {key, source index}: one element per lane
 // up to 64 keys, stable rank when that is exact, the wave-parallel introsort restatement otherwise.
-template <bool GREATER>
-__device__ __forceinline__ void wave_sort_staged(ElimLds& L, int cnt, int lane) {
+template <bool GREATER, int EC>
+__device__ __forceinline__ void wave_sort_staged(ElimLdsT<EC>& L, int cnt, int lane) {
     if (cnt <= 64) {
         double key = lane < cnt ? L.skey[lane] : 0.0;
         int idx = lane, pos = lane;
@@ -888,8 +889,8 @@ __device__ __forceinline__ void wave_sort_staged(ElimLds& L, int cnt, int lane) 
     const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
     for (int i = lane; i < cnt; i += 64) { L.rec[i].key = L.skey[i]; L.rec[i].idx = i; }
     WAVE_SYNC();
-    if (GREATER) wave_std_sort<SRec, SRecGreaterKey, ECAP / 64>(L.rec, cnt, SRecGreaterKey(), WP, lane);
-    else wave_std_sort<SRec, SRecLessKey, ECAP / 64>(L.rec, cnt, SRecLessKey(), WP, lane);
+    if (GREATER) wave_std_sort<SRec, SRecGreaterKey, EC / 64>(L.rec, cnt, SRecGreaterKey(), WP, lane);
+    else wave_std_sort<SRec, SRecLessKey, EC / 64>(L.rec, cnt, SRecLessKey(), WP, lane);
     WAVE_SYNC();
 }
 
@@ -910,8 +911,9 @@ __device__ __forceinline__ int32_t alloc_in_column(const Arrays& A, int32_t& a, 
 
 __device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Single-vertex path, executed by ONE wave (columns up to ECAP entries, multi-edges, any key range).
-__device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLds& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
+// Single-vertex path, executed by ONE wave (columns up to EC entries, multi-edges, any key range).
+template <int EC>
+__device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLdsT<EC>& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
                                int32_t acnt, int32_t abase, long long* wprof) {
     const int lane = lane_id();
     long long wt_prev = wprof ? wall_clock64() : 0;
@@ -1041,7 +1043,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 
     WSTAMP(3);
     double* cum = reinterpret_cast<double*>(L.rec);
-    double* newv = cum + ECAP;
+    double* newv = cum + EC;
     int32_t status = 0;
     int koff_c = 0;        // coarsen: chosen position
     double wk_c = 0;
@@ -1054,7 +1056,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
         for (int j0 = 0; j0 < m; j0 += 8) {
             double vv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < ECAP ? j0 + u : ECAP - 1];
+            for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < EC ? j0 + u : EC - 1];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { if (j0 + u < m) { csum += vv[u]; cum[j0 + u] = csum; } }
         }
@@ -1063,7 +1065,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             for (int j0 = 0; j0 < m - 1; j0 += 8) {
                 double vv[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < ECAP ? j0 + u : ECAP - 1];
+                for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < EC ? j0 + u : EC - 1];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (j0 + u < m - 1) {
@@ -1116,8 +1118,8 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             const int j = j0 + lane;
             const bool act = j < m - 1;
             const int x = act ? L.t_of[L.ksel[j]] : 0;
-            uint64_t mymask = __ballot(act);   // lanes that drew my target: one ballot per bit of its index (< ECAP <= 512)
-            static_assert(ECAP <= 512, "9 bits of target index");
+            uint64_t mymask = __ballot(act);   // lanes that drew my target: one ballot per bit of its index (< EC <= 512)
+            static_assert(EC <= 512 && EC % 64 == 0, "9 bits of target index");
 #pragma unroll
             for (int bit = 0; bit < 9; ++bit) {
                 const bool mybit = (x >> bit) & 1;
@@ -1451,7 +1453,7 @@ struct BatchLdsT {
 template <int BC, int NTT>
 union ElimSharedT {
     BatchLdsT<BC, NTT> b;
-    ElimLds e;
+    ElimLdsT<(NTT >= 1024 ? ECAP : ECAP_SMALL)> e;
     BigElimLdsT<(NTT >= 1024 ? 7168 : 1536)> g;
 };
 static_assert(sizeof(ElimSharedT<64, 1024>) == sizeof(BatchLdsT<64, 1024>) && sizeof(ElimSharedT<32, 1024>) == sizeof(BatchLdsT<32, 1024>),
@@ -1609,7 +1611,7 @@ __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G
 // Specialised on (o_v, o_n): the mode tests fold away, which keeps the round loop's code (executed once
 // per round by every wave) small enough for the instruction cache.
 template <int OV, int ON, int BC, int NTT>
-__global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
+__global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_t(Arrays A_in, GraphDesc* __restrict__ gd, ElimScratch S,
                                                            int32_t* __restrict__ batch_pos, const int32_t* __restrict__ in_flags,
                                                            const double* __restrict__ in_acc) {
     constexpr int NT = NTT;            // threads per workgroup
@@ -1639,8 +1641,14 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
     __shared__ GraphDesc G;
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end, s_anydep, s_npatched;
     constexpr int32_t POOL_GRAB = NT >= 1024 ? POOL_GRAB_BIG : POOL_GRAB_SMALL;   // slots reserved at a time for the round's appends
-    __shared__ uint8_t s_eqperm[BC - 16][BC];   // std::sort's permutation of n = 17..BC all-equal keys
-    __shared__ uint8_t s_eqinv[BC - 16][BC];    // its inverse: final position of the entry with id-rank r
+    // std::sort's permutation of n = 17..BC all-equal keys and its inverse (final position of the entry with id-rank r):
+    // in LDS for the 1024-thread shape; the 256-thread shape reads the handle's tables (k_eq_tables) through the L1,
+    // which leaves its LDS at 39 KB -- four workgroups per CU
+    constexpr bool EQG = NTT < 1024;
+    constexpr int EC1 = NTT >= 1024 ? ECAP : ECAP_SMALL;   // single-vertex path in LDS up to this extent
+    __shared__ uint8_t s_eqperm[EQG ? 1 : BC - 16][EQG ? 1 : BC];
+    __shared__ uint8_t s_eqinv[EQG ? 1 : BC - 16][EQG ? 1 : BC];
+    const uint8_t* __restrict__ eqg = S.eqtab + (BC == 64 ? 0 : EQTAB_OFF32);
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1653,17 +1661,19 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         else if (in_acc[2] != 0.0 || !(in_acc[0] <= 1e-24 * in_acc[1])) bad = ST_NOT_SYMMETRIC;   // isApprox(A^T), factorizers.cc:19-22
         s_status = bad;
     }
-    for (int base = 0; base < BC - 16; base += BATCH) {   // the candidate records serve as scratch: BATCH lengths at a time
-        const int row = base + tid;
-        if (tid < BATCH && row < BC - 16) {
-            Cand& C = L.cand[tid];
-            const int nn = 17 + row;
-            for (int q = 0; q < nn; ++q) { C.e[q].aux = 1.0; C.ksel[q] = (uint8_t)q; }
-            C.m = nn;
-            Arrays A3 = A;
-            cand_order_index_call(A3, C);   // all keys equal: asc and desc compare alike
-            for (int q = 0; q < BC; ++q) s_eqperm[row][q] = q < nn ? C.ksel[q] : (uint8_t)q;
-            for (int q = 0; q < BC; ++q) s_eqinv[row][s_eqperm[row][q]] = (uint8_t)q;
+    if constexpr (!EQG) {
+        for (int base = 0; base < BC - 16; base += BATCH) {   // the candidate records serve as scratch: BATCH lengths at a time
+            const int row = base + tid;
+            if (tid < BATCH && row < BC - 16) {
+                Cand& C = L.cand[tid];
+                const int nn = 17 + row;
+                for (int q = 0; q < nn; ++q) { C.e[q].aux = 1.0; C.ksel[q] = (uint8_t)q; }
+                C.m = nn;
+                Arrays A3 = A;
+                cand_order_index_call(A3, C);   // all keys equal: asc and desc compare alike
+                for (int q = 0; q < BC; ++q) s_eqperm[row][q] = q < nn ? C.ksel[q] : (uint8_t)q;
+                for (int q = 0; q < BC; ++q) s_eqinv[row][s_eqperm[row][q]] = (uint8_t)q;
+            }
         }
     }
     __syncthreads();
@@ -1698,7 +1708,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 ElimScratch S2 = S;
                 int32_t cp0 = A2.colptr[v0], cp1 = A2.colptr[v0 + 1];
                 int32_t acnt = A2.vr[v0].app_cnt, abase = A2.vr[v0].app_chunk;
-                if ((cp1 - cp0) + acnt > ECAP) {
+                if ((cp1 - cp0) + acnt > EC1) {
                     ColBuf Bf = S2.colbuf(G.scr_base);
                     const bool handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
                     if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
@@ -1829,7 +1839,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     const int32_t m = __popcll(half);
                     if (live) {
                         const int32_t r = __popcll(half & ~((2ull << e) - 1ull));
-                        const int32_t pos = (m <= 16) ? r : (int32_t)s_eqinv[m - 17][r];
+                        const int32_t pos = (m <= 16) ? r : (int32_t)(EQG ? eqg[(BC - 16) * BC + (m - 17) * BC + r] : s_eqinv[EQG ? 0 : m - 17][EQG ? 0 : r]);
                         Ent& E = C.e[pos];
                         E.val = lv[k]; E.nbr = ln[k]; E.twin = lt[k]; E.aux = 0;
                     }
@@ -2026,7 +2036,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                     Cand& C = L.cand[i];
                     const int32_t m = C.m;
                     if (hdiff == 0) {
-                        C.ksel[j] = (m <= 16) ? (uint8_t)j : s_eqperm[m - 17][j];
+                        C.ksel[j] = (m <= 16) ? (uint8_t)j : (EQG ? eqg[(m - 17) * BC + j] : s_eqperm[EQG ? 0 : m - 17][EQG ? 0 : j]);
                     } else {
                         int32_t r = 0; bool tie = false;
                         for (int32_t q = 0; q < m; ++q) {
@@ -2335,7 +2345,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
                 ElimScratch S2 = S;
                 int32_t cp0 = A2.colptr[v0], cp1 = A2.colptr[v0 + 1];
                 int32_t acnt = A2.vr[v0].app_cnt, abase = A2.vr[v0].app_chunk;
-                if ((cp1 - cp0) + acnt > ECAP) {
+                if ((cp1 - cp0) + acnt > EC1) {
                     bool handled = false;
                     if (OV == OV_RANDOM) {
                         ColBuf Bf = S2.colbuf(G.scr_base);
@@ -2805,6 +2815,35 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 3)) void k_eliminate_batch_
         if (S.prof && g == 0) { for (int q = 0; q < 20; ++q) S.prof[q] = s_prof[q]; S.prof[20] = clock64() - clk0; S.prof[21] = wall_clock64() - wall0; S.prof[22] = rounds; S.prof[23] = singles; for (int q = 24; q < 40; ++q) S.prof[q] = s_prof[q]; }
         gd[g] = G;
     }
+}
+
+// The handle's tables of std::sort's permutation of 17..BC all-equal keys (layout: rlap_kernels.h EQTAB_*), built once.
+template <int BC>
+__global__ __launch_bounds__(64) void k_eq_tables(uint8_t* __restrict__ out) {
+    __shared__ CandT<BC> c[16];
+    const int tid = threadIdx.x;
+    Arrays A = {};
+    A.o_v = OV_RANDOM; A.o_n = ON_ASC;   // all keys equal: asc and desc compare alike
+    for (int base = 0; base < BC - 16; base += 16) {
+        const int row = base + tid;
+        if (tid < 16 && row < BC - 16) {
+            CandT<BC>& C = c[tid];
+            const int nn = 17 + row;
+            for (int q = 0; q < nn; ++q) { C.e[q].aux = 1.0; C.ksel[q] = (uint8_t)q; }
+            C.m = nn;
+            cand_order_index_call(A, C);
+            uint8_t* perm = out + row * BC;
+            uint8_t* inv = out + (BC - 16) * BC + row * BC;
+            for (int q = 0; q < BC; ++q) perm[q] = q < nn ? C.ksel[q] : (uint8_t)q;
+            for (int q = 0; q < BC; ++q) inv[perm[q]] = (uint8_t)q;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_eq_tables(hipStream_t stream, uint8_t* out) {
+    hipLaunchKernelGGL(k_eq_tables<64>, dim3(1), dim3(64), 0, stream, out);
+    hipLaunchKernelGGL(k_eq_tables<32>, dim3(1), dim3(64), 0, stream, out + EQTAB_OFF32);
 }
 
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
