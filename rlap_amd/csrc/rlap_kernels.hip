@@ -2850,7 +2850,7 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t 
                             int32_t* batch_pos, const int32_t* flags, const double* acc) {
     // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
     // turn comes): it runs with 64 slots per candidate (64 candidates per round); the min-degree orders with 32.
-    // more graphs than CUs: the 256-thread shape, three workgroups per CU (measured on 4096-node graphs: the same
+    // more graphs than CUs: the 256-thread shape, four workgroups per CU (128 VGPRs, 39 KB of LDS; measured on 4096-node graphs: the same
     // time per graph as the 1024-thread shape, which is only ahead when one graph offers more than 32 independent vertices a round)
     if (n_cu <= 0) n_cu = 256;
     bool many = G > (unsigned)n_cu;

@@ -388,7 +388,7 @@ def test_batched_equals_separate_calls(ops):
 
 @pytest.mark.parametrize("o_v,o_n", [("degree", "asc"), ("degree", "random"), ("random", "asc"), ("random", "desc"), ("coarsen", "asc"), ("random", "random")])
 def test_batched_many_graphs(ops, o_v, o_n):
-    """More graphs than twice the CUs: the batch runs with the 256-thread workgroup shape (three per CU).
+    """More graphs than twice the CUs: the batch runs with the 256-thread workgroup shape (four per CU).
     Every 16th graph is compared with the oracle; sizes include dense ones whose columns leave the 32/64-slot
     candidates (single-vertex wave path) and a star whose centre needs the long-column path."""
     from rlap_amd import graphs
