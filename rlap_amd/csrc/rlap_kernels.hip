@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rlap_core.h"
 #include "rlap_kernels.h"
@@ -596,6 +597,165 @@ __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int
 }
 
 // ---------------------------------------------------------------------------
+// Level-synchronous form of the same restatement for n <= 64*REG elements in LDS (element p = lane p%64, turn p/64):
+// every segment of one recursion level is partitioned in the same pass, so a sort costs as many passes as the introsort
+// is deep (both halves of a partition run with the same decremented depth limit, and partitions of disjoint segments do
+// not see each other) instead of one pass per partition.  The segment starts are a bit mask (wave-uniform); the stop
+// lists of a segment are stored at the segment's own offset; ranks inside them are differences of per-position stop counts
+// (ballot popcounts, tabulated in LDS so that a segment reads the counts at its two ends):
+//   up-stop p, `cu` up-stops before it in its segment, `cd` down-stops behind it: it is u_cu and swaps iff d_cu > p
+//   iff cd > cu; a down-stop is d_cd and swaps iff u_cd < p iff cu > cd; with k swaps the cut min(u_k, d_{k-1}) is the
+//   up-stop with cu == k and cd >= k, or the down-stop with cd == k-1 and cu <= k.
+// Returns false when a segment longer than 16 meets depth limit 0 (std::sort heap-sorts it): the array is then
+// partly partitioned and the caller starts over with wave_std_sort on the original order.
+// ---------------------------------------------------------------------------
+template <class T, class Less, int REG>
+__device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* ulist, uint16_t* dlist, uint32_t* tab, uint16_t* tab2, int lane) {
+    if (n < 2) return true;
+    const uint64_t lt = lanemask_lt(lane);
+    const uint64_t le = lt | (1ull << lane);
+    const uint64_t gt = ~le;
+    uint64_t seg[REG];
+#pragma unroll
+    for (int t = 0; t < REG; ++t) seg[t] = 0ull;
+    seg[0] = 1ull;
+    int depth = 0;
+    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth;
+    depth *= 2;
+    int first[REG], last[REG];
+    while (true) {
+        // segment of every element: nearest start at or below / above its position
+        int prevw[REG], nextw[REG];
+        {
+            int run = 0;
+#pragma unroll
+            for (int t = 0; t < REG; ++t) { prevw[t] = run; if (seg[t]) run = 64 * t + 63 - __builtin_clzll(seg[t]); }
+            run = n;
+#pragma unroll
+            for (int t = REG - 1; t >= 0; --t) { nextw[t] = run; if (seg[t]) run = 64 * t + __builtin_ctzll(seg[t]); }
+        }
+        bool act[REG];
+        uint64_t anyact = 0ull;
+#pragma unroll
+        for (int t = 0; t < REG; ++t) {
+            const int p = lane + 64 * t;
+            const uint64_t lo = seg[t] & le, hi = seg[t] & gt;
+            first[t] = lo ? 64 * t + 63 - __builtin_clzll(lo) : prevw[t];
+            last[t] = hi ? 64 * t + __builtin_ctzll(hi) : nextw[t];
+            act[t] = p < n && last[t] - first[t] > 16;
+            anyact |= __ballot(act[t]);
+        }
+        if (!anyact) break;
+        if (depth == 0) return false;
+        --depth;
+        T xn[REG];
+        bool su[REG], sd[REG], moved[REG];
+        uint64_t MU[REG], MD[REG];
+#pragma unroll
+        for (int t = 0; t < REG; ++t) {
+            const int p = lane + 64 * t;
+            su[t] = false; sd[t] = false; moved[t] = false;
+            if (act[t]) {
+                // __move_median_to_first(first, first+1, mid, last-1), then the pivot sits at `first`
+                const int f = first[t], ia = f + 1, ib = f + (last[t] - f) / 2, ic = last[t] - 1;
+                const T A = a[ia], B = a[ib], C = a[ic], F = a[f], X = a[p];
+                int pick; T P;
+                if (less(A, B)) {
+                    if (less(B, C)) { pick = ib; P = B; }
+                    else if (less(A, C)) { pick = ic; P = C; }
+                    else { pick = ia; P = A; }
+                } else if (less(A, C)) { pick = ia; P = A; }
+                else if (less(B, C)) { pick = ic; P = C; }
+                else { pick = ib; P = B; }
+                xn[t] = (p == f) ? P : ((p == pick) ? F : X);
+                moved[t] = (p == f) || (p == pick);
+                su[t] = p > f && !less(xn[t], P);
+                sd[t] = p > f && !less(P, xn[t]);
+            }
+            MU[t] = __ballot(su[t]);
+            MD[t] = __ballot(sd[t]);
+        }
+        // stops in front of every position (up-stops in the low half, down-stops in the high half): a segment reads the
+        // entries at its two ends instead of counting over the masks
+        int cumU = 0, cumD = 0;
+#pragma unroll
+        for (int t = 0; t < REG; ++t) {
+            const int p = lane + 64 * t;
+            if (p < n) tab[p] = (uint32_t)(cumU + popc64(MU[t] & lt)) | ((uint32_t)(cumD + popc64(MD[t] & lt)) << 16);
+            cumU += popc64(MU[t]); cumD += popc64(MD[t]);
+        }
+        const uint32_t tab_n = (uint32_t)cumU | ((uint32_t)cumD << 16);
+        WAVE_SYNC();
+        int cu[REG], cd[REG];
+        bool swu[REG], swd[REG];
+        uint64_t SW[REG];
+        cumU = 0; cumD = 0;
+#pragma unroll
+        for (int t = 0; t < REG; ++t) {
+            swu[t] = false; swd[t] = false; cu[t] = 0; cd[t] = 0;
+            if (act[t]) {
+                const uint32_t x1 = tab[first[t] + 1], xl = (last[t] == n) ? tab_n : tab[last[t]];
+                cu[t] = cumU + popc64(MU[t] & lt) - (int)(x1 & 0xFFFFu);     // up-stops before me in my segment
+                cd[t] = (int)(xl >> 16) - (cumD + popc64(MD[t] & le));        // down-stops behind me
+                swu[t] = su[t] && cd[t] > cu[t];
+                swd[t] = sd[t] && cu[t] > cd[t];
+                if (su[t]) ulist[first[t] + cu[t]] = (uint16_t)(lane + 64 * t);
+                if (sd[t]) dlist[first[t] + cd[t]] = (uint16_t)(lane + 64 * t);
+            }
+            cumU += popc64(MU[t]); cumD += popc64(MD[t]);
+            SW[t] = __ballot(swu[t]);
+        }
+        int cumS = 0;
+#pragma unroll
+        for (int t = 0; t < REG; ++t) {
+            const int p = lane + 64 * t;
+            if (p < n) tab2[p] = (uint16_t)(cumS + popc64(SW[t] & lt));
+            cumS += popc64(SW[t]);
+        }
+        WAVE_SYNC();
+        uint64_t CUT[REG];
+#pragma unroll
+        for (int t = 0; t < REG; ++t) {
+            bool iscut = false;
+            if (act[t]) {
+                const int k = (int)((last[t] == n) ? (uint16_t)cumS : tab2[last[t]]) - (int)tab2[first[t] + 1];   // swaps of my segment
+                iscut = (su[t] && cu[t] == k && cd[t] >= k) || (sd[t] && k >= 1 && cd[t] == k - 1 && cu[t] <= k);
+                int dest = lane + 64 * t;
+                if (swu[t]) dest = dlist[first[t] + cu[t]];
+                if (swd[t]) dest = ulist[first[t] + cd[t]];
+                if (swu[t] || swd[t] || moved[t]) a[dest] = xn[t];
+            }
+            CUT[t] = __ballot(iscut);
+        }
+        WAVE_SYNC();
+#pragma unroll
+        for (int t = 0; t < REG; ++t) seg[t] |= CUT[t];
+    }
+    // final insertion sort == stable order inside every segment (all of them <= 16 elements now)
+    T vv[REG];
+    int rr[REG];
+#pragma unroll
+    for (int t = 0; t < REG; ++t) {
+        const int p = lane + 64 * t;
+        rr[t] = -1;
+        if (p < n) {
+            const T v = a[p];
+            int r = first[t];
+            for (int q = first[t]; q < last[t]; ++q) {
+                const T x = a[q];
+                r += (q != p && (less(x, v) || (!less(v, x) && q < p))) ? 1 : 0;
+            }
+            vv[t] = v; rr[t] = r;
+        }
+    }
+    WAVE_SYNC();
+#pragma unroll
+    for (int t = 0; t < REG; ++t) if (rr[t] >= 0) a[rr[t]] = vv[t];
+    WAVE_SYNC();
+    return true;
+}
+
+// ---------------------------------------------------------------------------
 // The same restatement for n <= 64 with ONE ELEMENT PER LANE (key and source index in registers):
 // partitions exchange elements with ds_bpermute instead of LDS round trips, the two stop lists are
 // rank-indexed lane ids in a 2 x 66 int LDS scratch, the segment marks are one 64-bit mask and the
@@ -817,51 +977,11 @@ struct ElimLdsT {
     int32_t b_slot[EC], b_nbr[EC], b_twin[EC], b_pos[EC], b_dup[EC];
     int32_t ksel[EC], t_key[EC], t_mv[EC], t_of[EC], t_cnt[EC], t_chunk[EC], t_list[EC], t_rank[EC], pslot[EC];
     WaveSortScratchT<EC> ws;
-    alignas(16) double skey[EC + 8];   // sort keys, contiguous (rank sort reads them 8 at a time)
+    alignas(16) double skey[EC + 8];   // sort keys as staged (kept: a sort that meets the depth limit starts over from them)
 };
 
-// Rank sort == any stable sort. Exact w.r.t. std::sort when cnt <= 16 (pure
-// insertion sort, stable) or when all keys are distinct (unique answer).
-// Returns true if it wrote rec[rank] = {key, idx}; false if ties need the
-// sequential emulation.
-template <bool GREATER, int EC>
-__device__ __forceinline__ bool wave_rank_sort(ElimLdsT<EC>& L, int cnt, int lane) {   // keys staged in L.skey[0..cnt)
-    // only this wave is running (the others wait at a barrier): LDS latency is exposed, so the keys are read
-    // eight at a time before they are compared.  NaN padding compares false with everything.
-    const int cpad = (cnt + 7) & ~7;
-    for (int q = cnt + lane; q < cpad; q += 64) L.skey[q] = __builtin_nan("");
-    WAVE_SYNC();
-    bool dup = false;
-    for (int i = lane; i < cnt; i += 64) {
-        const double ki = L.skey[i];
-        int rank = 0, eqc = 0;
-        for (int j = 0; j < cpad; j += 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = L.skey[j + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool before = GREATER ? (v[u] > ki) : (v[u] < ki);
-                const bool eq = (v[u] == ki);
-                rank += (before || (eq && (j + u) < i)) ? 1 : 0;
-                eqc += eq ? 1 : 0;
-            }
-        }
-        dup |= eqc > 1;
-        L.t_rank[i] = rank;
-    }
-    bool anydup = __ballot(dup) != 0ull;
-    if (cnt > 16 && anydup) return false;
-    for (int i = lane; i < cnt; i += 64) {
-        int r = L.t_rank[i];
-        L.rec[r].key = L.skey[i];
-        L.rec[r].idx = i;
-    }
-    return true;
-}
-
 // std::sort order of the staged keys L.skey[0..cnt) into L.rec[] = {key, source index}: one element per lane
-// up to 64 keys, stable rank when that is exact, the wave-parallel introsort restatement otherwise.
+// up to 64 keys, the level-synchronous introsort restatement beyond.
 template <bool GREATER, int EC>
 __device__ __forceinline__ void wave_sort_staged(ElimLdsT<EC>& L, int cnt, int lane) {
     if (cnt <= 64) {
@@ -873,24 +993,24 @@ __device__ __forceinline__ void wave_sort_staged(ElimLdsT<EC>& L, int cnt, int l
             WAVE_SYNC();
             return;
         }
-    } else {
-        // a stable rank is only exact without ties: probe a few neighbours first (unit weights tie at once)
-        bool tie = false;
-        for (int i = lane; i < cnt; i += 64) {
-            const double ki = L.skey[i];
-            tie |= (i + 1 < cnt && L.skey[i + 1] == ki) || (i + 2 < cnt && L.skey[i + 2] == ki) || (i + 5 < cnt && L.skey[i + 5] == ki);
-        }
-        if (__ballot(tie) == 0ull && wave_rank_sort<GREATER>(L, cnt, lane)) {
-            WAVE_SYNC();
-            return;
-        }
     }
     WAVE_SYNC();
     const WaveSortPtrs WP = {L.ws.ulist, L.ws.dlist, L.ws.segmark, L.ws.stk};
     for (int i = lane; i < cnt; i += 64) { L.rec[i].key = L.skey[i]; L.rec[i].idx = i; }
     WAVE_SYNC();
-    if (GREATER) wave_std_sort<SRec, SRecGreaterKey, EC / 64>(L.rec, cnt, SRecGreaterKey(), WP, lane);
-    else wave_std_sort<SRec, SRecLessKey, EC / 64>(L.rec, cnt, SRecLessKey(), WP, lane);
+    // beyond 64 keys: the introsort restatement, one pass per recursion level (wave_lvl_sort; exact with or without ties -- a
+    // stable rank costs as much and is only exact without them); its depth-limit exit starts over.  t_rank / pslot are free here.
+    typedef typename std::conditional<GREATER, SRecGreaterKey, SRecLessKey>::type Cmp;
+    bool ok;
+    if (cnt <= 128) ok = wave_lvl_sort<SRec, Cmp, 2>(L.rec, cnt, Cmp(), L.ws.ulist, L.ws.dlist, reinterpret_cast<uint32_t*>(L.t_rank), reinterpret_cast<uint16_t*>(L.pslot), lane);
+    else if (cnt <= 256) ok = wave_lvl_sort<SRec, Cmp, 4>(L.rec, cnt, Cmp(), L.ws.ulist, L.ws.dlist, reinterpret_cast<uint32_t*>(L.t_rank), reinterpret_cast<uint16_t*>(L.pslot), lane);
+    else ok = wave_lvl_sort<SRec, Cmp, EC / 64>(L.rec, cnt, Cmp(), L.ws.ulist, L.ws.dlist, reinterpret_cast<uint32_t*>(L.t_rank), reinterpret_cast<uint16_t*>(L.pslot), lane);
+    if (!ok) {
+        WAVE_SYNC();
+        for (int i = lane; i < cnt; i += 64) { L.rec[i].key = L.skey[i]; L.rec[i].idx = i; }
+        WAVE_SYNC();
+        wave_std_sort<SRec, Cmp, EC / 64>(L.rec, cnt, Cmp(), WP, lane);
+    }
     WAVE_SYNC();
 }
 
@@ -2915,6 +3035,8 @@ __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict
     __shared__ SRec rec[SCAP];
     __shared__ WaveSortScratch W;
     __shared__ int32_t tmp64[160];
+    __shared__ uint32_t ltab[SCAP];
+    __shared__ uint16_t ltab2[SCAP];
     const int lane = lane_id();
     for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
         const int32_t o = offs[arr], n = offs[arr + 1] - o;
@@ -2943,7 +3065,18 @@ __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict
             __syncthreads();
             continue;
         }
-        if (desc & 1) wave_std_sort<SRec>(rec, n, SRecGreaterKey(), WP, lane); else wave_std_sort<SRec>(rec, n, SRecLessKey(), WP, lane);
+        if (desc & 8) {   // level-synchronous variant (single-vertex path, long columns of the output pass)
+            bool ok;
+            if (n <= 128) ok = (desc & 1) ? wave_lvl_sort<SRec, SRecGreaterKey, 2>(rec, n, SRecGreaterKey(), W.ulist, W.dlist, ltab, ltab2, lane) : wave_lvl_sort<SRec, SRecLessKey, 2>(rec, n, SRecLessKey(), W.ulist, W.dlist, ltab, ltab2, lane);
+            else if (n <= 256) ok = (desc & 1) ? wave_lvl_sort<SRec, SRecGreaterKey, 4>(rec, n, SRecGreaterKey(), W.ulist, W.dlist, ltab, ltab2, lane) : wave_lvl_sort<SRec, SRecLessKey, 4>(rec, n, SRecLessKey(), W.ulist, W.dlist, ltab, ltab2, lane);
+            else ok = (desc & 1) ? wave_lvl_sort<SRec, SRecGreaterKey, 8>(rec, n, SRecGreaterKey(), W.ulist, W.dlist, ltab, ltab2, lane) : wave_lvl_sort<SRec, SRecLessKey, 8>(rec, n, SRecLessKey(), W.ulist, W.dlist, ltab, ltab2, lane);
+            if (!ok) {   // depth limit: start over on the original order
+                __syncthreads();
+                for (int q = lane; q < n; q += 64) { rec[q].key = keys[o + q]; rec[q].idx = q; rec[q].aux = 0; }
+                __syncthreads();
+                if (desc & 1) wave_std_sort<SRec>(rec, n, SRecGreaterKey(), WP, lane); else wave_std_sort<SRec>(rec, n, SRecLessKey(), WP, lane);
+            }
+        } else if (desc & 1) wave_std_sort<SRec>(rec, n, SRecGreaterKey(), WP, lane); else wave_std_sort<SRec>(rec, n, SRecLessKey(), WP, lane);
         __syncthreads();
         for (int q = lane; q < n; q += 64) perm_out[o + q] = rec[q].idx;
         __syncthreads();

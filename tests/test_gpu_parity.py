@@ -35,9 +35,22 @@ def gpu_call(ops, ei, w, n, t, o_v, o_n, perm=None, seed=0):
     return out.numpy()
 
 
+def _where(a, b):
+    """First differing row and the extent of the difference (which column, how many of its rows, same multiset or not)."""
+    d = np.flatnonzero((a != b).any(axis=1))
+    if d.size == 0:
+        return ""
+    col = a[d[0], 1]
+    rows = np.flatnonzero(a[:, 1] == col)
+    same_set = sorted(map(tuple, a[rows].tolist())) == sorted(map(tuple, b[rows].tolist()))
+    return (f" [{d.size} rows differ, first {d[0]}: got {a[d[0]].tolist()} expected {b[d[0]].tolist()}; column {int(col)} has {rows.size} rows "
+            f"({int((a[rows] != b[rows]).any(axis=1).sum())} differ, same rows in another order: {same_set}); columns touched: "
+            f"{np.unique(a[d, 1]).size}]")
+
+
 def assert_same(a, b, what=""):
     assert a.shape == b.shape, f"{what}: rows {a.shape} vs {b.shape}"
-    assert np.array_equal(a[:, :2], b[:, :2]), f"{what}: indices differ"
+    assert np.array_equal(a[:, :2], b[:, :2]), f"{what}: indices differ" + _where(a, b)
     assert np.array_equal(a[:, 2], b[:, 2]), f"{what}: weights differ, max abs {np.abs(a[:, 2] - b[:, 2]).max()}"
 
 
@@ -78,8 +91,9 @@ def test_wave_parallel_std_sort_matches_libstdcxx(ops):
     offs_t = torch.from_numpy(offs).cuda()
     lib, h = ops._handle(torch.device("cuda", 0))
     # bit 0: descending; bit 1: arrays of <= 64 elements go through the register-resident variant (one wave per array);
-    # bit 2: the half-wave variant, two arrays of <= 32 elements side by side (longer ones are skipped)
-    for desc in (0, 1, 2, 3, 4, 5):
+    # bit 2: the half-wave variant, two arrays of <= 32 elements side by side (longer ones are skipped);
+    # bit 3: the level-synchronous variant (every segment of a recursion level partitioned in the same pass)
+    for desc in (0, 1, 2, 3, 4, 5, 8, 9):
         out = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device="cuda")
         rc = lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr())
         assert rc == 0
@@ -105,7 +119,7 @@ def test_sorts_follow_the_depth_limit_branch(ops):
     keys = torch.from_numpy(np.concatenate(arrays)).cuda()
     offs_t = torch.from_numpy(offs).cuda()
     lib, h = ops._handle(torch.device("cuda", 0))
-    for desc in (0, 1, 2, 3):
+    for desc in (0, 1, 2, 3, 8, 9):   # (8: the level-synchronous variant reports the depth limit, the hook starts over with the LDS variant)
         out = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device="cuda")
         assert lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr()) == 0
         got = out.cpu().numpy()
@@ -536,6 +550,21 @@ def test_config5_full_size(ops, config5, o_v, o_n, every):
         got = sc[int(rp[g]):int(rp[g + 1])].copy()
         got[:, :2] -= g * n
         assert_same(got, ref, f"config 5 graph {g} {o_v}/{o_n}")
+
+
+@pytest.mark.parametrize("o_v", ["degree", "random"])
+def test_config5_run_to_run(ops, config5, o_v):
+    """The batched call is deterministic: slots of the append pool are handed to the 1024 workgroups in whatever order they
+    ask, the rows returned must not depend on it (20 runs compared on the device)."""
+    G, n, eis, big, node_ptr, perms = config5
+    perm = torch.from_numpy(np.concatenate(perms)) if o_v == "random" else None
+    first = None
+    for it in range(20):
+        sc, rp = ops.approximate_cholesky_batched(big, None, node_ptr, [n // 2] * G, o_v, "asc", perm=perm, seed=5, return_device="same")
+        if first is None:
+            first = sc.clone()
+        else:
+            assert sc.shape == first.shape and bool(torch.equal(sc, first)), f"run {it} differs from run 0" + _where(sc.cpu().numpy(), first.cpu().numpy())
 
 
 def test_bad_perm_is_rejected(ops):
