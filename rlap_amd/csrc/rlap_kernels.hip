@@ -1031,10 +1031,66 @@ __device__ __forceinline__ int32_t alloc_in_column(const Arrays& A, int32_t& a, 
 
 __device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// The f / colScale / wdeg recurrence (:396-417): new weight of every position but the last.  One lane; the operation order is the result.
+template <int EC>
+__device__ __forceinline__ void new_weights(const double* a_val, double* newv, int m, double csum) {
+    double wdeg = csum, colScale = 1;
+    for (int j0 = 0; j0 < m - 1; j0 += 8) {
+        double vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = a_val[j0 + u < EC ? j0 + u : EC - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (j0 + u < m - 1) {
+                double w = vv[u] * colScale;
+                double f = w / wdeg;
+                double omf = 1 - f;
+                newv[j0 + u] = f * omf * wdeg;
+                colScale = colScale * omf;
+                wdeg = wdeg * omf * omf;
+            }
+        }
+    }
+}
+
+constexpr int HELP_MIN = 24;   // columns shorter than this keep the recurrence on the eliminating wave (the hand-over costs about a microsecond)
+
+// Wave 1 while wave 0 runs the single-vertex path: waits for the request, runs the recurrence over the ordered weights, reports.
+// (csum is recomputed here: the same left-to-right sum the eliminating wave forms for the cumulative weights.)
+template <int EC>
+__device__ __noinline__ void single_helper(ElimLdsT<EC>& L, int32_t* help) {
+    const int lane = lane_id();
+    int f = 0;
+    if (lane == 0) {
+        int sp = 0;
+        while ((f = __hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 1 && f != 3 && ++sp < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+    }
+    f = __shfl(f, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (f != 1) {
+        if (lane == 0 && f == 3) __hip_atomic_store(&help[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    if (lane == 0) {
+        const int m = help[1];
+        double csum = 0;
+        for (int j0 = 0; j0 < m; j0 += 8) {
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < EC ? j0 + u : EC - 1];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < m) csum += vv[u];
+        }
+        new_weights<EC>(L.a_val, reinterpret_cast<double*>(L.rec) + EC, m, csum);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&help[0], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
 // Single-vertex path, executed by ONE wave (columns up to EC entries, multi-edges, any key range).
 template <int EC>
 __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimLdsT<EC>& L, int32_t v, int64_t e1, int32_t cp0, int32_t cp1,
-                               int32_t acnt, int32_t abase, long long* wprof) {
+                               int32_t acnt, int32_t abase, long long* wprof, int32_t* help) {
     const int lane = lane_id();
     long long wt_prev = wprof ? wall_clock64() : 0;
 #define WSTAMP(k) do { if (wprof && lane == 0) { long long _t = wall_clock64(); wprof[k] += _t - wt_prev; wt_prev = _t; } } while (0)
@@ -1169,6 +1225,17 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     double wk_c = 0;
 
     // ---- cumulative weights + the f / colScale / wdeg recurrences (:366-417) ----
+    // The second recurrence (the new weights) is not needed before the rewire: wave 1 of the workgroup, idle otherwise, runs it
+    // (single_helper) while this wave samples and hands out the slots.  help[0]: 0 idle, 1 request (help[1] = m), 2 done, 3 no request.
+    const bool helped = !coarsen && m >= HELP_MIN;
+    if (helped && lane == 0) {
+        help[1] = m;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&help[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#define HELP_FINISH() do { if (helped) { if (lane == 0) { int _sp = 0; while (__hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 && ++_sp < (1 << 22)) __builtin_amdgcn_s_sleep(1); \
+        __hip_atomic_store(&help[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); WAVE_SYNC(); } \
+        else if (lane == 0) __hip_atomic_store(&help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     if (lane == 0) {
         // the two recurrences are the result's operation order: one lane, values fetched eight at a time
         // (nothing else runs on the CU now, so every LDS round trip would be waited for)
@@ -1180,32 +1247,14 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 #pragma unroll
             for (int u = 0; u < 8; ++u) { if (j0 + u < m) { csum += vv[u]; cum[j0 + u] = csum; } }
         }
-        if (!coarsen) {
-            double wdeg = csum, colScale = 1;
-            for (int j0 = 0; j0 < m - 1; j0 += 8) {
-                double vv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) vv[u] = L.a_val[j0 + u < EC ? j0 + u : EC - 1];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (j0 + u < m - 1) {
-                        double w = vv[u] * colScale;
-                        double f = w / wdeg;
-                        double omf = 1 - f;
-                        newv[j0 + u] = f * omf * wdeg;
-                        colScale = colScale * omf;
-                        wdeg = wdeg * omf * omf;
-                    }
-                }
-            }
-        }
+        if (!coarsen && !helped) new_weights<EC>(L.a_val, newv, m, csum);
     }
     WAVE_SYNC();
     WSTAMP(4);
     const double csum = m > 0 ? cum[m - 1] : 0.0;
     const int64_t draws0 = G.n_draws;
     int ndraw = coarsen ? (m >= 1 ? 1 : 0) : (m > 1 ? m - 1 : 0);
-    if (draws0 + ndraw > A.rng_len) { if (lane == 0) G.status = ST_RNG_OVERFLOW; WAVE_SYNC(); return; }
+    if (draws0 + ndraw > A.rng_len) { HELP_FINISH(); if (lane == 0) G.status = ST_RNG_OVERFLOW; WAVE_SYNC(); return; }
 
     if (coarsen) {
         if (m >= 1) {
@@ -1294,6 +1343,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
             L.t_list[x] = mv >= 0 ? pq_list_of(key, G.n) : -1;
         }
     }
+    HELP_FINISH();   // (the new weights are in place from here on)
     if (__ballot(status != 0) != 0ull) { if (lane == 0) G.status = ST_POOL_OVERFLOW; WAVE_SYNC(); return; }
     WAVE_SYNC();
 
@@ -1352,6 +1402,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     WAVE_SYNC();
     WSTAMP(8);
 #undef WSTAMP
+#undef HELP_FINISH
 }
 
 
@@ -1759,6 +1810,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     A.shuffle_seed = A_in.shuffle_seed + (uint64_t)blockIdx.x;   // graph g of a batch: seed + g, ids local to the graph (rlap_core.h)
     __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
+    __shared__ int32_t s_help[2];      // hand-over between the eliminating wave and its helper (single_helper)
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end, s_anydep, s_npatched;
     constexpr int32_t POOL_GRAB = NT >= 1024 ? POOL_GRAB_BIG : POOL_GRAB_SMALL;   // slots reserved at a time for the round's appends
     // std::sort's permutation of n = 17..BC all-equal keys and its inverse (final position of the entry with id-rank r):
@@ -1774,6 +1826,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     const int tid = threadIdx.x;
     if (tid == 0) {
         G = gd[g]; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0; s_anydep = 0; s_npatched = 0;
+        s_help[0] = 0; s_help[1] = 0;
         // the input checks of the setup kernels are read here, not on the host (no mid-call synchronisation): bad input -> nothing is eliminated
         int32_t bad = 0;
         if (in_flags[FLAG_RANGE]) bad = ST_INDEX_RANGE;
@@ -1832,9 +1885,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     ColBuf Bf = S2.colbuf(G.scr_base);
                     const bool handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
                     if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
+                    if (lane == 0) __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr);
+                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr, s_help);
                 }
+            } else if (tid < 128) {
+                single_helper(sh.e, s_help);
             }
             __syncthreads();
             if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
@@ -2472,9 +2528,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
                     }
                     if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
+                    if (lane == 0) __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr);
+                    wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr, s_help);
                 }
+            } else if (tid < 128) {
+                single_helper(sh.e, s_help);
             }
             if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_anydep = 0; s_npatched = 0; }
             __syncthreads();
