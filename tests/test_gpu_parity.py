@@ -611,6 +611,27 @@ def test_overflow_retry_path(ops, kind):
     assert_same(got, ref, f"after retry {kind}")
 
 
+@pytest.mark.parametrize("o_v", ["degree", "random"])
+def test_overflow_retry_path_batched(ops, config5, o_v):
+    """The same in a batched call: some of the 1024 workgroups meet the limit in the middle of a round, others finish; the
+    repeated attempt must not see anything of the first one."""
+    G, n, eis, big, node_ptr, perms = config5
+    perm = torch.from_numpy(np.concatenate(perms)) if o_v == "random" else None
+    ref, rp0 = ops.approximate_cholesky_batched(big, None, node_ptr, [n // 2] * G, o_v, "asc", perm=perm, seed=5, return_device="same")
+    assert ops.last_stats["n_retries"] == 0
+    for lim in (dict(pool_factor=0.0), dict(log_factor=0.0), dict(rng_len=1000)):
+        if o_v == "random" and "log_factor" in lim:
+            continue   # no PQ log in this mode
+        ops.debug_set_limits(**lim)
+        try:
+            sc, rp = ops.approximate_cholesky_batched(big, None, node_ptr, [n // 2] * G, o_v, "asc", perm=perm, seed=5, return_device="same")
+            retries = ops.last_stats["n_retries"]
+        finally:
+            ops.debug_set_limits()
+        assert retries > 0, f"{lim}: the limit was not hit"
+        assert sc.shape == ref.shape and bool(torch.equal(sc, ref)), f"{o_v} {lim}: differs after {retries} retries" + _where(sc.cpu().numpy(), ref.cpu().numpy())
+
+
 def test_two_threads_two_streams(ops):
     """Re-entrancy (reference: a fresh ApproximateCholesky per call, py_api_binder.cc:57): two Python threads, each on
     its own stream, call the op concurrently; every result is bit-exact."""
