@@ -3534,12 +3534,13 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
     unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
     unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
     hipLaunchKernelGGL((k_sc_merge_t<192, 64>), dim3(g1), dim3(64), 0, s2, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + (size_t)S, counts + 1);
-    hipLaunchKernelGGL((k_sc_merge_t<SCAP, 192>), dim3(g2), dim3(64), 0, s2, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + 2 * (size_t)S, counts + 2);
     unsigned gh = (unsigned)(S < 256 * 32 * 4 ? (S + 1) / 2 : 256 * 32 * 4);
     if (gh == 0) gh = 1;
     hipLaunchKernelGGL(k_sc_merge_half, dim3(gh), dim3(64), 0, stream, A, gd, vgraph, order, tmp_off, tmp_nbr, tmp_val, cnt_out, live_total, lists + 5 * (size_t)S, counts + 5, lists, counts);
     unsigned g0 = (unsigned)(S < 256 * 32 * 4 ? S : 256 * 32 * 4);
     hipLaunchKernelGGL((k_sc_merge_t<64, -1>), dim3(g0), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists, counts);
+    // (the <=512 tier follows on the main stream: the second side stream is the longest chain otherwise -- config 5: 4.8 ms of kernels against 2.7 here)
+    hipLaunchKernelGGL((k_sc_merge_t<SCAP, 192>), dim3(g2), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + 2 * (size_t)S, counts + 2);
     if (fork) {
         (void)hipEventRecord(X.ev[1], s1);
         (void)hipEventRecord(X.ev[2], s2);
