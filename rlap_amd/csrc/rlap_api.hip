@@ -410,7 +410,11 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
 
     if (h->timing) HIPCHK(hipEventRecord(h->ev[1], s));
     // ---------------- elimination ----------------
-    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, h->n_cu, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>(), flags, acc);
+    // 128-slot candidates for o_v = random when the columns run long: 12 or more entries per vertex on average (from the input
+    // sizes: no read-back).  Measured (ms per call, 64 -> 128 slots): BA(1M,10) 2950 -> 2180, BA(169343,7) 260 -> 248, BA(4096,8)
+    // 10.2 -> 9.2; BA(20000,5) 23.0 -> 23.4 and sparser graphs lose (their rounds fill 64 candidates and get only 32)
+    const bool wide = c.o_v == OV_RANDOM && nnz_ub >= 12 * N && N >= 512;
+    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, h->n_cu, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>(), flags, acc, wide);
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
 

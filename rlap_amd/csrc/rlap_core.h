@@ -655,9 +655,10 @@ enum { CF_BIG = 1, CF_DUP = 2, CF_COMPLEX = 4, CF_DEP = 8, CF_TIE = 16, CF_NEQ =
 constexpr int DEPMAX = 4;   // dependent candidates with more earlier neighbours in the round than this cut it
 enum { TF_CONTENDED = 1 };
 
-// BC = live entries a candidate may hold (32: one half-wave per candidate, 64: one wave).
+// BC = live entries a candidate may hold (32: one half-wave per candidate, 64: one wave, 128: one wave, two entries per lane).
 template <int BC> struct CandPad {};
 template <> struct CandPad<64> { int64_t pad64; };   // keeps the LDS stride of CandT<64> off the 64-bank period
+template <> struct CandPad<128> { int64_t pad128; };
 template <int BC>
 struct CandT : CandPad<BC> {
     static constexpr int CAP = BC;
@@ -674,11 +675,11 @@ struct CandT : CandPad<BC> {
     int32_t ext;      // slots to read (appended + CSR), dead ones included
     int32_t nmv;      // PQ moves this candidate causes (counted during the replay; bounds the round's move list)
     int32_t nkill;    // merged multi-edges (o_v = random, 64-slot form): e[m .. m+nkill) hold the twins that die (:289)
-    int32_t cb[BC <= 32 ? 3 : 4];   // bases of the appended chunks
+    int32_t cb[BC <= 32 ? 3 : (BC <= 64 ? 4 : 5)];   // bases of the appended chunks (chunk_of(BC - 1) + 1)
     int32_t ndep;     // earlier candidates of the round this one is adjacent to (cand_patch), at most DEPMAX
     uint8_t dep[4];
     int64_t draw0;    // first uniform
-};   // 872 B (BC=32) / 1688 B (BC=64): word strides 218 / 422
+};   // 872 B (BC=32) / 1688 B (BC=64) / 3288 B (BC=128): word strides 218 / 422 / 822
 typedef CandT<BCAP> Cand;
 
 RLAP_HD TRes& ent_tres(Ent& e) { return e.res; }
@@ -726,7 +727,7 @@ RLAP_HD void cand_order_index(const Arrays& A, CT& C) {
 // fourth vertex met in random order on small dense graphs has one); the PQ orders send them to the
 // single-vertex path, where the DegreePQDec per merged entry (:291) is replayed.
 template <class CT>
-RLAP_HD bool cand_merges_multi_edges(const Arrays& A) { return CT::CAP == 64 && A.o_v == OV_RANDOM; }
+RLAP_HD bool cand_merges_multi_edges(const Arrays& A) { return CT::CAP >= 64 && A.o_v == OV_RANDOM; }
 
 // Candidate preparation in three steps so the loads can be spread over all
 // threads: cand_meta (one per candidate), cand_load (one per slot), cand_finish.
@@ -739,7 +740,7 @@ RLAP_HD void cand_meta(const Arrays& A, int32_t v, CT& C) {
     C.cp1 = cp1; C.acnt = acnt; C.ext = (cp1 - cp0) + acnt;
     if (C.ext > CT::CAP) { C.flags = CF_BIG; C.ext = 0; return; }
     if (acnt > 0) {
-        int ct = chunk_of(acnt - 1);            // <= 2 (CAP 32) / <= 3 (CAP 64) because acnt <= CAP
+        int ct = chunk_of(acnt - 1);            // <= 2 (CAP 32) / <= 3 (CAP 64) / <= 4 (CAP 128) because acnt <= CAP
         for (int c = ct; c >= 0; --c) { C.cb[c] = base; if (c > 0) base = A.e[base].nbr; }
     }
 }

@@ -24,7 +24,8 @@ struct CallResults {
 constexpr int ECAP = 384;  // elimination: column extent handled in LDS; longer -> sequential form in global scratch
 constexpr int ECAP_SMALL = 320;   // the same for the 256-thread shape (four workgroups per CU: 40 KB of LDS each)
 constexpr int EQTAB_OFF32 = 2 * 48 * 64;                 // equal-key permutation tables: 64-slot candidates first (perm, inverse), then 32-slot
-constexpr int EQTAB_BYTES = EQTAB_OFF32 + 2 * 16 * 32;
+constexpr int EQTAB_OFF128 = EQTAB_OFF32 + 2 * 16 * 32;     // ... then 128-slot
+constexpr int EQTAB_BYTES = EQTAB_OFF128 + 2 * 112 * 128;
 constexpr int SCAP = 512;  // output pass: same
 constexpr int BIGCAP = 7168;  // output pass, long columns: one workgroup, 125 KB LDS record array + 31 KB LDS stop lists of the sort
 constexpr int BIG_LDS_BYTES = BIGCAP * 16 + 2 * (BIGCAP + 2) * 2;
@@ -106,7 +107,7 @@ __global__ void k_bucket_bounds(const uint32_t* order, const VRec* vr, const int
                                 int32_t* ocur, int32_t* oend, int32_t* origpos);
 void launch_eq_tables(hipStream_t stream, uint8_t* out);
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
-                            int32_t* batch_pos, const int32_t* flags, const double* acc);
+                            int32_t* batch_pos, const int32_t* flags, const double* acc, bool wide);
 __global__ void k_sc_keys(const VRec* vr, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,
                           int32_t N, uint64_t* skey, uint32_t* sval);
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,

@@ -378,6 +378,11 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const VRec* 
 // beyond n) go through the single-vertex wave path or the sequential fallback.
 // ---------------------------------------------------------------------------
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))   // out-of-line functions see generic pointers otherwise
+#else
+#define ASSUME_LDS(p) ((void)0)
+#endif
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // ---------------------------------------------------------------------------
@@ -1773,6 +1778,250 @@ __device__ __noinline__ bool wave_patch(const Arrays& A, CT* cand, int32_t d, in
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Candidate preparation for 128-slot candidates (o_v = random on graphs whose columns run long: a column of 65..128 entries
+// no longer ends the round).  ONE wave per candidate, two entries per lane: entry e = lane came in as (v0, n0, t0, a0),
+// entry 64 + lane as (v1, ...); the caller has stored the raw (val, nbr) of every loaded slot at C.e[e].  Steps as in the
+// 32/64-slot code: rank by id among the live entries (std::sort order where ids repeat), multi-edges folded (:278-293),
+// o_n order with std::sort semantics (:295-307), permutation applied.  The sorts beyond 64 elements are the level-synchronous
+// restatement over an index array (the keys stay in the record).  scr: WIDE_SCR_BYTES of LDS owned by this wave.
+// ---------------------------------------------------------------------------
+constexpr int WIDE_SCR_BYTES = 2048;
+
+// Bitonic network over the 128 values a wave holds two per lane (element t*64 + lane in a[t]): ascending.  The exchanges
+// with distance 64 stay inside the lane, the others are xor-shuffles.  Only the first KMAX elements (a power of two) matter
+// to the caller, the rest is padding that compares last: the stages beyond KMAX are left out, and up to 64 the second register
+// is left alone.  The second form sorts (key, source) pairs by key, then source -- a stable order.
+template <int KMAX>
+__device__ __forceinline__ void wave_bitonic_t(unsigned long long (&a)[2], int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= KMAX; kk <<= 1) {
+#pragma unroll
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            if (jj == 64) {
+                if (a[1] < a[0]) { const unsigned long long t = a[0]; a[0] = a[1]; a[1] = t; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < (KMAX > 64 ? 2 : 1); ++t) {
+                    const int e = t * 64 + lane;
+                    const unsigned long long o = __shfl_xor(a[t], jj);
+                    const bool keep_min = (((e & jj) == 0) == ((e & kk) == 0));
+                    if (keep_min == (o < a[t])) a[t] = o;
+                }
+            }
+        }
+    }
+}
+template <int KMAX>
+__device__ __forceinline__ void wave_bitonic_t(unsigned long long (&a)[2], int (&s)[2], int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= KMAX; kk <<= 1) {
+#pragma unroll
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            if (jj == 64) {
+                if (a[1] < a[0] || (a[1] == a[0] && s[1] < s[0])) { const unsigned long long t = a[0]; a[0] = a[1]; a[1] = t; const int u = s[0]; s[0] = s[1]; s[1] = u; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < (KMAX > 64 ? 2 : 1); ++t) {
+                    const int e = t * 64 + lane;
+                    const unsigned long long o = __shfl_xor(a[t], jj);
+                    const int os = __shfl_xor(s[t], jj);
+                    const bool keep_min = (((e & jj) == 0) == ((e & kk) == 0));
+                    const bool other_less = o < a[t] || (o == a[t] && os < s[t]);
+                    if (keep_min == other_less) { a[t] = o; s[t] = os; }
+                }
+            }
+        }
+    }
+}
+__device__ __forceinline__ void wave_bitonic128(unsigned long long (&a)[2], int lane, int count) {   // count: elements that matter (wave-uniform)
+    if (count <= 16) wave_bitonic_t<16>(a, lane);
+    else if (count <= 32) wave_bitonic_t<32>(a, lane);
+    else if (count <= 64) wave_bitonic_t<64>(a, lane);
+    else wave_bitonic_t<128>(a, lane);
+}
+__device__ __forceinline__ void wave_bitonic128(unsigned long long (&a)[2], int (&s)[2], int lane, int count) {
+    if (count <= 16) wave_bitonic_t<16>(a, s, lane);
+    else if (count <= 32) wave_bitonic_t<32>(a, s, lane);
+    else if (count <= 64) wave_bitonic_t<64>(a, s, lane);
+    else wave_bitonic_t<128>(a, s, lane);
+}
+struct WideIdLess { const Ent* e; __device__ bool operator()(uint16_t a, uint16_t b) const { return e[a].nbr < e[b].nbr; } };
+struct WideAuxLess { const Ent* e; __device__ bool operator()(uint16_t a, uint16_t b) const { return e[a].aux < e[b].aux; } };
+struct WideAuxGreater { const Ent* e; __device__ bool operator()(uint16_t a, uint16_t b) const { return e[a].aux > e[b].aux; } };
+
+__device__ __noinline__ void cand_prepare_wide(const Arrays& A, CandT<128>& C, int32_t vbase, double v0, int32_t n0, int32_t t0, bool a0,
+                                               double v1, int32_t n1, int32_t t1, bool a1, uint8_t* scr, const uint8_t* __restrict__ eqg) {
+    ASSUME_LDS(&C); ASSUME_LDS(scr);
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt(lane);
+    const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
+    const bool desc = (A.o_n == ON_DESC) && !keyed;
+    uint16_t* const rec = reinterpret_cast<uint16_t*>(scr);
+    uint16_t* const ulist = reinterpret_cast<uint16_t*>(scr + 256);
+    uint16_t* const dlist = reinterpret_cast<uint16_t*>(scr + 520);
+    uint32_t* const tab = reinterpret_cast<uint32_t*>(scr + 784);
+    uint16_t* const tab2 = reinterpret_cast<uint16_t*>(scr + 1296);
+    uint8_t* const posmap = scr + 1552;
+    int32_t* const tmp64 = reinterpret_cast<int32_t*>(scr);   // wave_sort64's scratch (never live together with the arrays above)
+    static_assert(1552 + 128 <= WIDE_SCR_BYTES && 256 * 4 <= WIDE_SCR_BYTES, "scratch layout");
+    const int32_t ext = C.ext;   // slots loaded (dead ones included)
+    const bool live0 = a0 && v0 > 0, live1 = a1 && v1 > 0;
+    const uint64_t h0 = __ballot(live0), h1 = __ballot(live1);
+    const int32_t nlive = popc64(h0) + popc64(h1);
+    // ---- rank by id among the live entries (dead ones last); equal ids = multi-edges.  Key = (id, place in the traversal
+    //      order): the network's order is the stable one, i.e. the insertion sort's ----
+    unsigned long long ik[2];
+    ik[0] = ((unsigned long long)(live0 ? (uint32_t)n0 : 0x7FFFFFFFu) << 8) | (unsigned)lane;
+    ik[1] = ((unsigned long long)(live1 ? (uint32_t)n1 : 0x7FFFFFFFu) << 8) | (unsigned)(64 + lane);
+    wave_bitonic128(ik, lane, ext);   // (slots e >= ext hold nothing)
+    bool anydup;
+    {
+        unsigned long long pv0 = __shfl_up(ik[0], 1), pv1 = __shfl_up(ik[1], 1);
+        const unsigned long long edge = __shfl(ik[0], 63);
+        if (lane == 0) { pv0 = ~0ull; pv1 = edge; }
+        const bool du0 = (ik[0] >> 8) == (pv0 >> 8) && (ik[0] >> 8) != 0x7FFFFFFFull;
+        const bool du1 = (ik[1] >> 8) == (pv1 >> 8) && (ik[1] >> 8) != 0x7FFFFFFFull;
+        anydup = (__ballot(du0) | __ballot(du1)) != 0ull;
+    }
+    posmap[(int)(ik[0] & 0xFFull)] = (uint8_t)lane;
+    posmap[(int)(ik[1] & 0xFFull)] = (uint8_t)(64 + lane);
+    WAVE_SYNC();   // (also: the raw entries stored by the caller)
+    const int32_t r0 = posmap[lane], r1 = posmap[64 + lane];
+    WAVE_SYNC();
+    int32_t rk0 = r0, rk1 = r1;
+    bool merge = false;
+    if (anydup) {
+        merge = true;
+        if (nlive > 16) {   // (up to 16: insertion sort, the stable order above)
+            // std::sort by id of the live entries in traversal order
+            const int g0 = popc64(h0 & lt), g1 = popc64(h0) + popc64(h1 & lt);
+            if (live0) rec[g0] = (uint16_t)lane;
+            if (live1) rec[g1] = (uint16_t)(64 + lane);
+            WAVE_SYNC();
+            bool ok;
+            if (nlive <= 64) {
+                const int src = lane < nlive ? (int)rec[lane] : 0;
+                WAVE_SYNC();
+                double key = (double)C.e[src].nbr;
+                int idx = src, pos = lane;
+                ok = wave_sort64<false>(key, idx, nlive, lane, tmp64, &pos);
+                WAVE_SYNC();
+                if (ok && lane < nlive) posmap[idx] = (uint8_t)pos;
+            } else {
+                ok = wave_lvl_sort<uint16_t, WideIdLess, 2>(rec, nlive, WideIdLess{C.e}, ulist, dlist, tab, tab2, lane);
+                if (ok) {
+                    if (lane < nlive) posmap[rec[lane]] = (uint8_t)lane;
+                    if (64 + lane < nlive) posmap[rec[64 + lane]] = (uint8_t)(64 + lane);
+                }
+            }
+            WAVE_SYNC();
+            if (!ok) {   // depth limit of the introsort: the single-vertex path takes this vertex
+                if (lane == 0) atomicOr(&C.flags, CF_DUP);
+                WAVE_SYNC();
+                return;
+            }
+            if (live0) rk0 = posmap[lane];
+            if (live1) rk1 = posmap[64 + lane];
+        }
+    }
+    WAVE_SYNC();   // every read of the raw entries is done
+    const uint64_t kb = keyed ? keyed_order_base(A.shuffle_seed, C.v - vbase, 0) : 0ull;
+    if (live0) { Ent& E = C.e[rk0]; E.val = v0; E.nbr = n0; E.twin = t0; E.aux = keyed ? keyed_order_dkey(kb, n0 - vbase) : v0; }
+    if (live1) { Ent& E = C.e[rk1]; E.val = v1; E.nbr = n1; E.twin = t1; E.aux = keyed ? keyed_order_dkey(kb, n1 - vbase) : v1; }
+    WAVE_SYNC();
+    int32_t m = nlive;
+    if (merge) {
+        // fold equal ids: the sum runs in sorted order (:284); the twins of the folded entries die at commit (:289)
+        const bool c0 = lane < nlive, c1 = 64 + lane < nlive;
+        const int32_t nb0 = c0 ? C.e[lane].nbr : -1, nb1 = c1 ? C.e[64 + lane].nbr : -1;
+        const int32_t tw0 = c0 ? C.e[lane].twin : 0, tw1 = c1 ? C.e[64 + lane].twin : 0;
+        double s0 = c0 ? C.e[lane].val : 0.0, s1 = c1 ? C.e[64 + lane].val : 0.0;
+        const int32_t pv0 = (c0 && lane > 0) ? C.e[lane - 1].nbr : -2, pv1 = c1 ? C.e[63 + lane].nbr : -2;
+        const bool hd0 = c0 && nb0 != pv0, hd1 = c1 && nb1 != pv1;
+        const uint64_t hm0 = __ballot(hd0), hm1 = __ballot(hd1);
+        m = popc64(hm0) + popc64(hm1);
+        if (hd0) {
+            const uint64_t above = (lane == 63) ? 0ull : (hm0 >> (lane + 1));
+            const int nexthead = above ? (lane + 1 + __builtin_ctzll(above)) : (hm1 ? 64 + __builtin_ctzll(hm1) : nlive);
+            for (int q = lane + 1; q < nexthead; ++q) s0 += C.e[q].val;
+        }
+        if (hd1) {
+            const uint64_t above = (lane == 63) ? 0ull : (hm1 >> (lane + 1));
+            const int nexthead = above ? (64 + lane + 1 + __builtin_ctzll(above)) : nlive;
+            for (int q = 64 + lane + 1; q < nexthead; ++q) s1 += C.e[q].val;
+        }
+        const uint64_t nh0 = __ballot(c0 && !hd0), nh1 = __ballot(c1 && !hd1);
+        const int32_t x0 = popc64(hm0 & lt), x1 = popc64(hm0) + popc64(hm1 & lt);
+        const int32_t y0 = popc64(nh0 & lt), y1 = popc64(nh0) + popc64(nh1 & lt);
+        WAVE_SYNC();
+        if (hd0) { Ent& E = C.e[x0]; E.val = s0; E.nbr = nb0; E.twin = tw0; E.aux = keyed ? keyed_order_dkey(kb, nb0 - vbase) : s0; }
+        else if (c0) C.e[m + y0].twin = tw0;
+        WAVE_SYNC();   // (a lane's first entry may land where another lane's second one was read: all reads are above)
+        if (hd1) { Ent& E = C.e[x1]; E.val = s1; E.nbr = nb1; E.twin = tw1; E.aux = keyed ? keyed_order_dkey(kb, nb1 - vbase) : s1; }
+        else if (c1) C.e[m + y1].twin = tw1;
+        if (lane == 0) { C.m = m; C.nkill = nlive - m; }
+        WAVE_SYNC();
+    } else if (lane == 0) C.m = nlive;
+    if (m == 0) { WAVE_SYNC(); return; }
+    // ---- o_n order: ksel[position] = source ----
+    const bool c0 = lane < m, c1 = 64 + lane < m;
+    const double k0 = c0 ? C.e[lane].aux : 0.0, k1 = c1 ? C.e[64 + lane].aux : 0.0;
+    const double kfirst = C.e[0].aux;
+    const bool alleq = (__ballot(c0 && k0 != kfirst) | __ballot(c1 && k1 != kfirst)) == 0ull;
+    if (alleq) {   // std::sort of all-equal keys: identity up to 16, a fixed permutation above (k_eq_tables)
+        if (c0) C.ksel[lane] = (m <= 16) ? (uint8_t)lane : eqg[(m - 17) * 128 + lane];
+        if (c1) C.ksel[64 + lane] = eqg[(m - 17) * 128 + 64 + lane];
+    } else {
+        // stable rank by (key, position): a bitonic network over the keys' bit patterns (weights and keyed keys are positive
+        // doubles: the patterns order like the values; complemented for the descending order); exact for m <= 16 (insertion
+        // sort) and whenever no two keys are equal
+        unsigned long long ok2[2];
+        int os2[2] = {lane, 64 + lane};
+        ok2[0] = c0 ? (desc ? ~(unsigned long long)__double_as_longlong(k0) : (unsigned long long)__double_as_longlong(k0)) : ~0ull;
+        ok2[1] = c1 ? (desc ? ~(unsigned long long)__double_as_longlong(k1) : (unsigned long long)__double_as_longlong(k1)) : ~0ull;
+        wave_bitonic128(ok2, os2, lane, m);
+        bool anytie;
+        {
+            unsigned long long pv0 = __shfl_up(ok2[0], 1), pv1 = __shfl_up(ok2[1], 1);
+            const unsigned long long edge = __shfl(ok2[0], 63);
+            if (lane == 0) pv1 = edge;
+            anytie = (__ballot(c0 && lane > 0 && ok2[0] == pv0) | __ballot(c1 && ok2[1] == pv1)) != 0ull;
+        }
+        if (m <= 16 || !anytie) {
+            if (c0) C.ksel[lane] = (uint8_t)os2[0];
+            if (c1) C.ksel[64 + lane] = (uint8_t)os2[1];
+        } else {
+            bool ok;
+            if (m <= 64) {
+                double key = k0;
+                int idx = lane, pos = lane;
+                ok = desc ? wave_sort64<true>(key, idx, m, lane, tmp64, &pos) : wave_sort64<false>(key, idx, m, lane, tmp64, &pos);
+                if (ok && lane < m) C.ksel[pos] = (uint8_t)idx;
+            } else {
+                if (c0) rec[lane] = (uint16_t)lane;
+                if (c1) rec[64 + lane] = (uint16_t)(64 + lane);
+                WAVE_SYNC();
+                ok = desc ? wave_lvl_sort<uint16_t, WideAuxGreater, 2>(rec, m, WideAuxGreater{C.e}, ulist, dlist, tab, tab2, lane)
+                          : wave_lvl_sort<uint16_t, WideAuxLess, 2>(rec, m, WideAuxLess{C.e}, ulist, dlist, tab, tab2, lane);
+                if (ok) { if (c0) C.ksel[lane] = (uint8_t)rec[lane]; if (c1) C.ksel[64 + lane] = (uint8_t)rec[64 + lane]; }
+            }
+            WAVE_SYNC();
+            if (!ok && lane == 0) cand_order_index_call(A, C);   // depth limit: the sequential restatement
+        }
+    }
+    WAVE_SYNC();
+    // ---- apply the permutation ----
+    double pv0 = 0, pv1 = 0; int32_t pn0 = 0, pn1 = 0, pt0 = 0, pt1 = 0;
+    if (c0) { const Ent& Sx = C.e[C.ksel[lane]]; pv0 = Sx.val; pn0 = Sx.nbr; pt0 = Sx.twin; }
+    if (c1) { const Ent& Sx = C.e[C.ksel[64 + lane]]; pv1 = Sx.val; pn1 = Sx.nbr; pt1 = Sx.twin; }
+    WAVE_SYNC();
+    if (c0) { Ent& E = C.e[lane]; E.val = pv0; E.nbr = pn0; E.twin = pt0; E.aux = 0; }
+    if (c1) { Ent& E = C.e[64 + lane]; E.val = pv1; E.nbr = pn1; E.twin = pt1; E.aux = 0; }
+    if (lane == 0) C.ndraw = (A.o_v == OV_COARSEN) ? 1 : (m > 1 ? m - 1 : 0);
+    WAVE_SYNC();
+}
+
 __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G, const ElimScratch& S, int32_t v0, int64_t e1) {
     ColBuf Bf = S.colbuf(G.scr_base);
     int rc = serial_eliminate(A, G, Bf, G.scr_cap, v0, e1);
@@ -1797,13 +2046,13 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     constexpr int BATCH = SLOTS / BC;
     typedef CandT<BC> Cand;
     typedef BatchLdsT<BC, NTT> BatchLds;
-    constexpr bool MERGE = (BC == 64 && OV == OV_RANDOM);           // multi-edges merged inside the candidate (rlap_core.h::cand_merges_multi_edges)
+    constexpr bool MERGE = (BC >= 64 && OV == OV_RANDOM);           // multi-edges merged inside the candidate (rlap_core.h::cand_merges_multi_edges)
     // candidates adjacent to earlier ones of the round are patched in LDS (rlap_core.h::cand_patch).  Measured: pays for the degree
     // order (C3 369 -> 274 ms); with o_v = random (64-slot candidates; wave_patch handles them too) the rounds of config 5 get 6.5 %
     // fewer and no faster, and the coarsening order fills its rounds without it -- so only the degree order uses it.
     constexpr bool PATCH = (OV == OV_DEGREE);
-    constexpr int GSH = 64 - BC;                                  // lane & GSH = first lane of my group
-    constexpr uint64_t GMASK = BC == 64 ? ~0ull : 0xFFFFFFFFull;   // a group's part of a 64-bit ballot
+    constexpr int GSH = BC >= 64 ? 0 : 64 - BC;                   // lane & GSH = first lane of my group
+    constexpr uint64_t GMASK = BC >= 64 ? ~0ull : 0xFFFFFFFFull;   // a group's part of a 64-bit ballot
     Arrays A = A_in;
     A.o_v = OV;
     A.o_n = ON;
@@ -1816,11 +2065,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     // std::sort's permutation of n = 17..BC all-equal keys and its inverse (final position of the entry with id-rank r):
     // in LDS for the 1024-thread shape; the 256-thread shape reads the handle's tables (k_eq_tables) through the L1,
     // which leaves its LDS at 39 KB -- four workgroups per CU
-    constexpr bool EQG = NTT < 1024;
+    constexpr bool EQG = NTT < 1024 || BC == 128;
     constexpr int EC1 = NTT >= 1024 ? ECAP : ECAP_SMALL;   // single-vertex path in LDS up to this extent
     __shared__ uint8_t s_eqperm[EQG ? 1 : BC - 16][EQG ? 1 : BC];
     __shared__ uint8_t s_eqinv[EQG ? 1 : BC - 16][EQG ? 1 : BC];
-    const uint8_t* __restrict__ eqg = S.eqtab + (BC == 64 ? 0 : EQTAB_OFF32);
+    const uint8_t* __restrict__ eqg = S.eqtab + (BC == 64 ? 0 : (BC == 32 ? EQTAB_OFF32 : EQTAB_OFF128));
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1969,13 +2218,16 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
         const bool first_is_big = (L.cand[0].flags & CF_BIG) != 0;   // goes to the single-vertex path: skip this round's prepare
         if (!first_is_big) {
             // BATCH*BCAP = 4*NT slots: issue every load before the first LDS store
-            static_assert(BATCH * BCAP == PASSES * NT && (BC == 32 || BC == 64), "slot loops are unrolled for PASSES passes");
+            static_assert(BATCH * BCAP == PASSES * NT && (BC == 32 || BC == 64 || BC == 128), "slot loops are unrolled for PASSES passes");
+            // slot of pass k -> (candidate, entry).  128-slot candidates: a wave owns a candidate, its entries lane and 64 + lane are
+            // the wave's passes 2c and 2c+1 (everything candidate-local stays inside one wave)
+            auto SI = [&](int k) -> int32_t { return BC == 128 ? ((k >> 1) * NWAVE + (tid >> 6)) : (k * NT + tid) / BCAP; };
+            auto SE = [&](int k) -> int32_t { return BC == 128 ? (((k & 1) << 6) + (tid & 63)) : (k * NT + tid) % BCAP; };
             double lv[PASSES]; int32_t ln[PASSES], lt[PASSES]; bool la[PASSES];
             const int32_t cut0 = (OV == OV_RANDOM) ? s_pmax : nc;   // o_v = random: the first long column (most rounds have one) is known already
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t idx = k * NT + tid;
-                const int32_t i = idx / BCAP, e = idx % BCAP;
+                const int32_t i = SI(k), e = SE(k);
                 la[k] = (i < nc) && (OV != OV_RANDOM || i < cut0) && (e < L.cand[i].ext);
                 lv[k] = 0; ln[k] = 0; lt[k] = 0;
                 if (la[k]) {
@@ -1994,6 +2246,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             // fixed permutation above: every entry goes straight to its final position.
             const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
             bool ready[PASSES];
+#pragma unroll
+            for (int k = 0; k < PASSES; ++k) ready[k] = false;
+            if constexpr (BC <= 64) {
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t idx = k * NT + tid;
@@ -2027,17 +2282,17 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     la[k] = false;   // nothing left to do for this slot
                 }
             }
+            }
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
                 if (la[k]) {
-                    const int32_t idx = k * NT + tid;
-                    Ent& E = L.cand[idx / BCAP].e[idx % BCAP];
+                    Ent& E = L.cand[SI(k)].e[SE(k)];
                     E.val = lv[k]; E.nbr = ln[k];
                 }
             }
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t i = (k * NT + tid) / BCAP;
+                const int32_t i = SI(k);
                 if (bpk[k] >= 0 && bpk[k] < i) {
                     if (PATCH) {
                         // adjacent to an earlier candidate of the round: remembered, patched after that one is sampled (wave_patch)
@@ -2051,8 +2306,22 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             __syncthreads();
             const int32_t ncp = s_pmax < nc ? s_pmax : nc;   // candidates [ncp, nc) are behind the cut
 #pragma unroll
-            for (int k = 0; k < PASSES; ++k) if ((k * NT + tid) / BCAP >= ncp) { la[k] = false; ready[k] = false; }
+            for (int k = 0; k < PASSES; ++k) if (SI(k) >= ncp) { la[k] = false; ready[k] = false; }
             PHASE_STAMP(9);
+            if constexpr (BC == 128) {
+                // 128-slot candidates: the wave prepares its (at most two) candidates one after the other (cand_prepare_wide);
+                // sort scratch in the hash / slot tables, which are idle until the barrier that ends P1
+                uint8_t* const wscr = reinterpret_cast<uint8_t*>(L.hcnt) + (size_t)(tid >> 6) * WIDE_SCR_BYTES;
+                static_assert((size_t)NWAVE * WIDE_SCR_BYTES <= sizeof(int32_t) * 8 * (size_t)NT, "scratch of the waves fits hcnt + pslot");
+#pragma unroll
+                for (int cc = 0; cc < PASSES / 2; ++cc) {
+                    const int32_t i = cc * NWAVE + (tid >> 6);
+                    if (i < ncp && !(L.cand[i].flags & CF_BIG)) {   // (wave-uniform)
+                        Arrays A3 = A;
+                        cand_prepare_wide(A3, L.cand[i], G.vbase, lv[2 * cc], ln[2 * cc], lt[2 * cc], la[2 * cc], lv[2 * cc + 1], ln[2 * cc + 1], lt[2 * cc + 1], la[2 * cc + 1], wscr, eqg);
+                    }
+                }
+            } else {
             // rank of every live entry among its column's live entries by id: with distinct ids the
             // sorted order is unique, so no std::sort emulation is needed (equal ids -> single-vertex path).
             // One half-wave = one candidate.  A column without appended entries whose CSR segment is still
@@ -2311,6 +2580,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     E.val = pv[k]; E.nbr = pn[k]; E.twin = pt[k]; E.aux = 0;
                 }
             }
+            }   // BC <= 64
         }
         __syncthreads();
         PHASE_STAMP(1);
@@ -2570,13 +2840,17 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             if (chead) { ca0 = A.vr[me.x].app_cnt; cchunk0 = A.vr[me.x].app_chunk; }
             // which positions of candidate me.i push into this target: found here by every record's own thread, so that
             // the group walk below only steps through the set bits (the unsorted record list is free: used as scratch)
-            uint64_t pm = 0ull;
+            uint64_t pm = 0ull, pm_hi = 0ull;
             if (me.i < P) {
                 const Cand& C = L.cand[me.i];
-                if (A.o_v == OV_COARSEN) { if (me.j == C.koff) pm = ((C.m >= 64 ? ~0ull : ((1ull << C.m) - 1ull)) & ~(1ull << C.koff)); }
-                else for (int32_t p = 0; p < C.m - 1; ++p) pm |= (C.ksel[p] == me.j) ? (1ull << p) : 0ull;
+                if (BC <= 64 && A.o_v == OV_COARSEN) { if (me.j == C.koff) pm = ((C.m >= 64 ? ~0ull : ((1ull << C.m) - 1ull)) & ~(1ull << C.koff)); }
+                else for (int32_t p = 0; p < C.m - 1; ++p) {
+                    const bool hit = (C.ksel[p] == me.j);
+                    if (BC <= 64 || p < 64) pm |= hit ? (1ull << (p & 63)) : 0ull; else pm_hi |= hit ? (1ull << (p & 63)) : 0ull;
+                }
             }
             L.cont[tid].x = (int32_t)(uint32_t)pm; L.cont[tid].j = (int32_t)(uint32_t)(pm >> 32);
+            if (BC == 128) L.mkey[tid] = pm_hi;   // (128-slot candidates: o_v = random only, no PQ moves -- the move list is free)
         }
         // targets touched by one candidate only: one thread per (candidate, target); two passes so that
         // all loads are in flight together and the pool is bumped once per round
@@ -2678,9 +2952,13 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 int32_t key_final = 0, mvseq = -1;
                 for (int32_t r = q; r < ncont && csorted[r].x == x && csorted[r].i < P; ++r) {
                     Cand& C = L.cand[csorted[r].i];
-                    uint64_t pm = ((uint64_t)(uint32_t)L.cont[r].j << 32) | (uint32_t)L.cont[r].x;
                     int32_t* pslot_row = &L.pslot[csorted[r].i * BCAP];
+                    uint64_t pm = ((uint64_t)(uint32_t)L.cont[r].j << 32) | (uint32_t)L.cont[r].x;
                     while (pm && status == 0) { const int p = __builtin_ctzll(pm); pm &= pm - 1; pslot_row[p] = alloc_in_column(A, a, chunk, &status); }
+                    if constexpr (BC == 128) {
+                        uint64_t ph = L.mkey[r];
+                        while (ph && status == 0) { const int p = __builtin_ctzll(ph); ph &= ph - 1; pslot_row[64 + p] = alloc_in_column(A, a, chunk, &status); }
+                    }
                     TRes R = ent_tres(C.e[csorted[r].j]);
                     key_final = R.key_after;
                     if (R.mv >= 0) mvseq = (csorted[r].i << 8) | R.mv;
@@ -3023,10 +3301,11 @@ __global__ __launch_bounds__(64) void k_eq_tables(uint8_t* __restrict__ out) {
 void launch_eq_tables(hipStream_t stream, uint8_t* out) {
     hipLaunchKernelGGL(k_eq_tables<64>, dim3(1), dim3(64), 0, stream, out);
     hipLaunchKernelGGL(k_eq_tables<32>, dim3(1), dim3(64), 0, stream, out + EQTAB_OFF32);
+    hipLaunchKernelGGL(k_eq_tables<128>, dim3(1), dim3(64), 0, stream, out + EQTAB_OFF128);
 }
 
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
-                            int32_t* batch_pos, const int32_t* flags, const double* acc) {
+                            int32_t* batch_pos, const int32_t* flags, const double* acc, bool wide) {
     // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
     // turn comes): it runs with 64 slots per candidate (64 candidates per round); the min-degree orders with 32.
     // more graphs than CUs: the 256-thread shape, four workgroups per CU (128 VGPRs, 39 KB of LDS; measured on 4096-node graphs: the same
@@ -3034,6 +3313,16 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t 
     if (n_cu <= 0) n_cu = 256;
     bool many = G > (unsigned)n_cu;
     if (const char* e = std::getenv("RLAP_BATCH_SHAPE")) { if (e[0] == '2') many = true; else if (e[0] == '1') many = false; }   // diagnostic override: 256 / 1024
+    // o_v = random on graphs with long columns (`wide`, chosen by the caller from the entries per vertex): 128 slots per
+    // candidate, 32 candidates per round -- a column of 65..128 entries no longer ends the round (BA(4096,8): 134 rounds + 13
+    // single vertices instead of 148 + 60).  Sparse graphs fill their rounds with 64 slots and keep 64 candidates.
+    if (const char* e = std::getenv("RLAP_WIDE")) { if (e[0] == '1') wide = true; else if (e[0] == '0') wide = false; }   // diagnostic override
+    if (wide && !many && o_v == OV_RANDOM) {
+        if (o_n == ON_ASC) hipLaunchKernelGGL((k_eliminate_batch_t<OV_RANDOM, ON_ASC, 128, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, flags, acc);
+        else if (o_n == ON_DESC) hipLaunchKernelGGL((k_eliminate_batch_t<OV_RANDOM, ON_DESC, 128, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, flags, acc);
+        else hipLaunchKernelGGL((k_eliminate_batch_t<OV_RANDOM, ON_RANDOM, 128, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, flags, acc);
+        return;
+    }
 #define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { \
         if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos, flags, acc); \
         else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, flags, acc); \

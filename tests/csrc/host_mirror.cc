@@ -446,10 +446,11 @@ int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const doubl
     return rc;
 }
 
-// same with the candidate capacity of the kernel variant (32 or 64) and the full statistics (13 values: + singles: total length, count and total length of those over 384 entries, max)
+// same with the candidate capacity of the kernel variant (32, 64 or 128) and the full statistics (13 values: + singles: total length, count and total length of those over 384 entries, max)
 int mirror_approx_chol_batch_bc(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
                                 int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t Bsz,
                                 int32_t bc, double** out, int64_t* out_rows, int64_t* order_out, int64_t* stats_out) {
+    if (bc == 128) return mirror_batch_impl<128>(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots, Bsz, out, out_rows, order_out, stats_out);
     if (bc == 64) return mirror_batch_impl<64>(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots, Bsz, out, out_rows, order_out, stats_out);
     return mirror_batch_impl<32>(row, col, w, E, n, t, o_v, o_n, perm, shuffle_seed, pool_slots, Bsz, out, out_rows, order_out, stats_out);
 }

@@ -142,10 +142,26 @@ def test_batch_rounds_equal_sequential_order(host_mirror, o_v, o_n):
         for t in sorted({1, n // 2, n - 1}):
             for wts in (None, sym_weights(ei, n, 5)):
                 a, oa = oracle.approximate_cholesky(ei, wts, n, t, o_v, o_n, perm=perm, shuffle_seed=3, return_order=True)
-                for B, bc in ((1, 32), (7, 32), (128, 32), (64, 64)):   # 64-slot candidates: the o_v="random" kernel variant
+                for B, bc in ((1, 32), (7, 32), (128, 32), (64, 64), (32, 128)):   # 64- / 128-slot candidates: the o_v="random" kernel variants
                     b, ob, _ = _mirror_batch(host_mirror, ei, wts, n, t, o_v, o_n, B, perm=perm, seed=3, bc=bc)
                     assert np.array_equal(oa, ob), (name, t, B, bc)
                     assert a.shape == b.shape and np.array_equal(a, b), (name, t, B, bc)
+
+
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_wide_candidates_equal_sequential_order(host_mirror, o_n):
+    """128-slot candidates (o_v="random" on graphs whose columns run long): dense graphs, where most columns have 65..128
+    entries and multi-edges appear at once, unit and tie-free weights."""
+    for n, m in ((400, 40), (900, 20), (150, 70)):
+        ei = ba_graph(n, m, 5)
+        perm = np.random.RandomState(11).permutation(n)
+        for wts in (None, sym_weights(ei, n, 5)):
+            a, oa = oracle.approximate_cholesky(ei, wts, n, n // 2, "random", o_n, perm=perm, shuffle_seed=3, return_order=True)
+            b, ob, st = _mirror_batch(host_mirror, ei, wts, n, n // 2, "random", o_n, 32, perm=perm, seed=3, bc=128)
+            assert np.array_equal(oa, ob), (n, m)
+            assert a.shape == b.shape and np.array_equal(a, b), (n, m)
+            b64, _, st64 = _mirror_batch(host_mirror, ei, wts, n, n // 2, "random", o_n, 64, perm=perm, seed=3, bc=64)
+            assert st[1] < st64[1], "fewer single-vertex fallbacks than with 64 slots"
 
 
 @pytest.mark.parametrize("o_v", ["degree", "random"])

@@ -240,6 +240,26 @@ def test_long_columns_random_order(ops, o_n):
             assert_same(b, a, f"{name} {o_n} {'unit' if w is None else 'weighted'}")
 
 
+@pytest.mark.parametrize("wide", ["1", "0"])
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_wide_candidates_random_order(ops, monkeypatch, o_n, wide):
+    """o_v="random", 128-slot candidates (chosen for graphs with 8 or more entries per vertex; RLAP_WIDE forces the choice either
+    way here): columns of 65..128 entries stay inside the round -- two entries per lane, multi-edges folded in the candidate,
+    both orders by the level-synchronous std::sort restatement over an index array.  Dense, sparse, weighted (tie-free) and
+    unit-weight (all ties) graphs, a star (the hub takes the long-column path), a grid."""
+    monkeypatch.setenv("RLAP_WIDE", wide)
+    cases = [("BA3000_12", ba_graph(3000, 12, 1), 3000), ("BA700_60", ba_graph(700, 60, 3), 700), ("BA260_100", ba_graph(260, 100, 4), 260),
+             ("BA20000_7", ba_graph(20000, 7, 5), 20000), ("BA2708_2", ba_graph(2708, 2, 6), 2708), ("star900", star(900), 900),
+             ("grid40x30", grid2d(40, 30), 1200), ("K90", clique(90), 90)]
+    for name, ei, n in cases:
+        perm = np.random.RandomState(len(name)).permutation(n)
+        for w in (None, sym_weights(ei, n, 9)):
+            for t in sorted({n // 2, n - 1}):
+                a = oracle.approximate_cholesky(ei, w, n, t, "random", o_n, perm=perm, shuffle_seed=6)
+                b = gpu_call(ops, ei, w, n, t, "random", o_n, perm=perm, seed=6)
+                assert_same(b, a, f"{name} t={t} {o_n} {'unit' if w is None else 'weighted'} wide={wide}")
+
+
 @pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
 def test_long_surviving_columns(ops, o_n):
     """Output pass: surviving columns beyond the 512-entry tiers (LDS record array, up to 8192 entries) and
