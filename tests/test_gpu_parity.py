@@ -258,6 +258,25 @@ def test_wide_candidates_random_order(ops, monkeypatch, o_n, wide):
                 a = oracle.approximate_cholesky(ei, w, n, t, "random", o_n, perm=perm, shuffle_seed=6)
                 b = gpu_call(ops, ei, w, n, t, "random", o_n, perm=perm, seed=6)
                 assert_same(b, a, f"{name} t={t} {o_n} {'unit' if w is None else 'weighted'} wide={wide}")
+    if o_n != "random":
+        # a hub of 65..128 neighbours whose weights are an introsort killer with ties: the level-synchronous sort of the candidate
+        # meets the depth limit and the sequential restatement takes over (heap-sort branch)
+        from util import introsort_killer
+        for n in (100, 128):
+            ei = star(n)
+            k, hit = introsort_killer(n - 1)
+            assert hit
+            hub = int(np.argmax(np.bincount(ei[0], minlength=n)))
+            leaf = np.where(ei[0] == hub, ei[1], ei[0])
+            rank_of_leaf = {int(v): i for i, v in enumerate(sorted(set(leaf.tolist())))}
+            kk = np.floor(k / 2)
+            w = np.array([1.0 + kk[rank_of_leaf[int(v)]] for v in leaf])
+            for first in (0, 3):   # the hub is popped first / after three leaves
+                rest = [v for v in range(n) if v != hub]
+                perm = np.array((rest[:first] + [hub] + rest[first:])[::-1])
+                a = oracle.approximate_cholesky(ei, w, n, 10, "random", o_n, perm=perm, shuffle_seed=6)
+                b = gpu_call(ops, ei, w, n, 10, "random", o_n, perm=perm, seed=6)
+                assert_same(b, a, f"killer star{n} hub@{first} {o_n} wide={wide}")
 
 
 @pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
