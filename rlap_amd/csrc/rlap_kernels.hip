@@ -2028,6 +2028,25 @@ __device__ __noinline__ void serial_eliminate_call(const Arrays& A, GraphDesc& G
     if (rc) G.status = rc;
 }
 
+// Which positions of my candidate drew ME as their target (ksel[p] == j)?  A group of BC lanes = the positions of one candidate:
+// lane p publishes ksel[p] bit by bit with ballots, lane j keeps the positions whose bits spell j.  Replaces the O(m) scan of
+// ksel every (candidate, target) thread made in the replay and again when the slots are handed out.  Every lane of the wave calls.
+template <int BC>
+__device__ __forceinline__ uint64_t group_pick_mask(const uint8_t* ksel, int32_t m, bool cand_ok, int lane) {
+    static_assert(BC == 32 || BC == 64, "one candidate per (half-)wave");
+    constexpr int BITS = BC == 32 ? 5 : 6;
+    const int gl = lane & (BC - 1), hb = lane & (64 - BC);
+    const bool vp = cand_ok && gl < m - 1;       // position gl draws a target
+    const int t = vp ? (int)ksel[gl] : 0;
+    uint64_t mm = __ballot(vp);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const uint64_t bb = __ballot(vp && ((t >> b) & 1));
+        mm &= ((gl >> b) & 1) ? bb : ~bb;
+    }
+    return (mm >> hb) & (BC == 64 ? ~0ull : 0xFFFFFFFFull);
+}
+
 // Specialised on (o_v, o_n): the mode tests fold away, which keeps the round loop's code (executed once
 // per round by every wave) small enough for the instruction cache.
 template <int OV, int ON, int BC, int NTT>
@@ -2120,6 +2139,13 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
         asm volatile("" : "+v"(tid_round));
         const int tid = tid_round;
         const int lane = tid & 63;
+        // thread <-> (candidate, position) in the replay and commit phases.  64-slot candidates (o_v = random): a wave is one candidate,
+        // so that its lanes can match positions and targets with ballots (group_pick_mask; config 5: 19.9 -> 18.6 ms).  The others keep
+        // the interleaved layout (8 or 32 lanes per candidate and pass) and scan ksel: with 32-slot candidates the grouped layout keeps all
+        // four passes busy where the interleaved one skips the last two for short candidates (measured: C3 285 -> 305 ms with it)
+        constexpr bool GROUPED = (BC == 64);
+        auto PI = [&](int k) -> int32_t { return GROUPED ? (k * NT + tid) / BCAP : tid / (NT / BATCH); };
+        auto PJ = [&](int k) -> int32_t { return GROUPED ? (k * NT + tid) % BCAP : k * (NT / BATCH) + tid % (NT / BATCH); };
         if (OV == OV_RANDOM && pending_long) {
             // the vertex that cut the previous round goes straight to the single-vertex path: no round is set up around it
             pending_long = false;
@@ -2667,7 +2693,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             int32_t key0k[PASSES];   // the targets' keys: fetched here, used after the barrier (their latency hides behind the table)
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                const int32_t i = PI(k), j = PJ(k);
                 key0k[k] = 1;
                 if (i >= Pmax) continue;
                 if (j < L.cand[i].m) {
@@ -2687,7 +2713,13 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             PHASE_STAMP(33);
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                const int32_t i = PI(k), j = PJ(k);
+                uint64_t pm = 0ull;
+                if constexpr (GROUPED) {
+                    if (__ballot(i < Pmax) == 0ull) continue;   // (wave-uniform)
+                    const bool cok = i < Pmax;
+                    pm = group_pick_mask<BC <= 64 ? BC : 64>(L.cand[cok ? i : 0].ksel, cok ? L.cand[i].m : 0, cok, lane);
+                }
                 if (i >= Pmax) continue;
                 Cand& C = L.cand[i];
                 if (j >= C.m) continue;
@@ -2700,7 +2732,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 if (tc > 1) {
                     // the key-independent half of the replay now, in parallel; the walk below chains the keys
                     int c0, li0;
-                    cand_replay_pre(A, C, j, &c0, &li0);
+                    if constexpr (GROUPED) { c0 = __popcll(pm); li0 = pm ? 63 - __builtin_clzll(pm) : -1; }
+                    else cand_replay_pre(A, C, j, &c0, &li0);
                     R.flags = TF_CONTENDED; R.mv = (int16_t)li0; R.c = (uint8_t)c0; R.key_after = 0;
                     int32_t q = atomicAdd(&s_ncont, 1);
                     if (q < CCAP) { L.cont[q].x = x; L.cont[q].i = i; L.cont[q].j = j; }
@@ -2709,7 +2742,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 }
                 const bool allow_last = (done + i + 1) + 1 < (int64_t)n;
                 int mv, c; bool cx = false;
-                int32_t k2 = cand_replay(A, C, j, key0, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
+                int32_t k2;
+                if constexpr (GROUPED) {
+                    c = __popcll(pm);
+                    k2 = cand_replay_post(A, C, j, key0, use_pq ? n : 0x7FFFFFFF, allow_last, c, pm ? 63 - __builtin_clzll(pm) : -1, &mv, &cx);
+                } else k2 = cand_replay(A, C, j, key0, use_pq ? n : 0x7FFFFFFF, allow_last, &mv, &c, &cx);
                 if (!use_pq) { mv = -1; cx = false; }
                 R.key_after = k2; R.mv = (int16_t)mv; R.c = (uint8_t)c; R.flags = 0;
                 if (cx) atomicMin(&s_p, i);   // keys beyond n: this candidate goes to the single-vertex path
@@ -2859,7 +2896,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             int32_t need_thread = 0;
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                const int32_t i = PI(k), j = PJ(k);
                 actk[k] = false; xk[k] = 0; a0k[k] = 0; chk[k] = -1; needk[k] = 0;
                 Rk[k].key_after = 0; Rk[k].mv = -1; Rk[k].c = 0; Rk[k].flags = 0;
                 if (i < P && j < L.cand[i].m) {
@@ -2904,11 +2941,26 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             int32_t cursor = pbase + nex;
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
-                const int32_t i = tid / (NT / BATCH), j = k * (NT / BATCH) + tid % (NT / BATCH);
+                const int32_t i = PI(k), j = PJ(k);
                 if (__ballot(actk[k]) == 0ull) continue;
+                uint64_t pm = 0ull;
+                if constexpr (GROUPED) {
+                    const bool cok = i < P;
+                    pm = group_pick_mask<BC <= 64 ? BC : 64>(L.cand[cok ? i : 0].ksel, cok ? L.cand[i].m : 0, cok, lane);
+                }
                 if (actk[k] && Rk[k].c > 0 && status == 0) {
                     const Cand& C = L.cand[i];
                     int32_t a = a0k[k], chunk = chk[k];
+                    if constexpr (GROUPED) {
+                        for (uint64_t mm = pm; mm; mm &= mm - 1) {   // the positions that push into this target, ascending
+                            const int p = __builtin_ctzll(mm);
+                            int c = chunk_of(a);
+                            int32_t cs = chunk_start(c);
+                            if (a == cs) { A.e[cursor].nbr = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
+                            L.pslot[i * BCAP + p] = chunk + 1 + (a - cs);
+                            ++a;
+                        }
+                    } else {
                     const bool co = A.o_v == OV_COARSEN;
                     const int32_t plast = co ? C.m : C.m - 1;
                     for (int32_t p = 0; p < plast; ++p) {
@@ -2918,6 +2970,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         if (a == cs) { A.e[cursor].nbr = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
                         L.pslot[i * BCAP + p] = chunk + 1 + (a - cs);
                         ++a;
+                    }
                     }
                     A.vr[xk[k]].app_cnt = a; A.vr[xk[k]].app_chunk = chunk;
                 }
