@@ -3430,7 +3430,13 @@ __global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __re
     ext[i] = (colptr[v + 1] - colptr[v]) + vr[v].app_cnt;
 }
 
-// test hook: one wave sorts one array of doubles, returns the permutation (tests/test_gpu_parity.py)
+struct RecKeyLessDbg { const SRec* r; __device__ bool operator()(uint16_t a, uint16_t b) const { return r[a].key < r[b].key; } };
+struct RecKeyGreaterDbg { const SRec* r; __device__ bool operator()(uint16_t a, uint16_t b) const { return r[a].key > r[b].key; } };
+// test hook: one wave sorts one array of doubles, returns the permutation (tests/test_gpu_parity.py).
+// CAUTION: an out-of-line function is compiled once for all its callers, with the loosest register budget among them.  This kernel
+// has none: calling an instantiation the elimination kernels use (e.g. wave_lvl_sort<SRec, .., 5 or 6>) from here lifts that
+// function beyond 128 VGPRs and takes the 256-thread shape from four workgroups per CU to two (tests/test_cabi_symbols.py checks the
+// register counts of the built kernels).
 __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict__ keys, const int32_t* __restrict__ offs, int32_t narr,
                                                         int32_t desc, int32_t* __restrict__ perm_out) {
     __shared__ SRec rec[SCAP];
@@ -3463,6 +3469,17 @@ __global__ __launch_bounds__(64) void k_debug_wave_sort(const double* __restrict
             int idx = lane, pos = lane;
             bool ok = (desc & 1) ? wave_sort64<true>(key, idx, n, lane, tmp64, &pos) : wave_sort64<false>(key, idx, n, lane, tmp64, &pos);
             if (lane < n) perm_out[o + (ok ? pos : lane)] = ok ? idx : -1;
+            __syncthreads();
+            continue;
+        }
+        if ((desc & 16) && n <= 128) {   // level-synchronous variant over an INDEX array, keys looked up by the comparison (128-slot candidates)
+            __shared__ uint16_t ord[128];
+            for (int q = lane; q < n; q += 64) ord[q] = (uint16_t)q;
+            __syncthreads();
+            const bool ok = (desc & 1) ? wave_lvl_sort<uint16_t, RecKeyGreaterDbg, 2>(ord, n, RecKeyGreaterDbg{rec}, W.ulist, W.dlist, ltab, ltab2, lane)
+                                       : wave_lvl_sort<uint16_t, RecKeyLessDbg, 2>(ord, n, RecKeyLessDbg{rec}, W.ulist, W.dlist, ltab, ltab2, lane);
+            __syncthreads();
+            for (int q = lane; q < n; q += 64) perm_out[o + q] = ok ? (int32_t)ord[q] : -1;
             __syncthreads();
             continue;
         }

@@ -40,3 +40,43 @@ def test_ops_refuse_to_run_without_gpu():
     from rlap_amd import ops
     with pytest.raises(RuntimeError):
         ops.approximate_cholesky(torch.tensor([[0, 1], [1, 0]]), None, 2, 1, "degree", "asc")
+
+
+def test_elimination_kernels_keep_their_register_and_lds_budget(tmp_path):
+    """The elimination kernels are built for 128 VGPRs (16 waves per CU) and, in the 256-thread shape, 40 KB of LDS (four
+    workgroups per CU).  Out-of-line device functions are compiled once for all their callers with the loosest budget among
+    them, so an innocent new caller (a test hook, say) can silently halve the occupancy of every kernel that shares the function:
+    read the numbers back from the code object inside the built library."""
+    import pytest
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM tools not found")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
+    subprocess.check_call([tools[0], "--dump-section", f".hip_fatbin={fat}", _lib.LIB_PATH, str(tmp_path / "unused.so")])
+    subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+    notes = subprocess.check_output([tools[2], "--notes", co], text=True)
+    kernels = {}
+    cur = {}
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(name|vgpr_count|group_segment_fixed_size):\s+(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2)
+        if key == "group_segment_fixed_size":     # first of the three keys of a kernel record (alphabetical order)
+            cur = {"lds": int(val)}
+        elif key == "name":
+            cur["name"] = val
+        elif key == "vgpr_count" and "name" in cur:
+            cur["vgpr"] = int(val)
+            kernels[cur["name"]] = cur
+    elim = {k: v for k, v in kernels.items() if "k_eliminate_batch_t" in k}
+    assert len(elim) >= 21, sorted(kernels)[:5]
+    for name, k in elim.items():
+        assert k["vgpr"] <= 128, (name, k)
+        if "ELi256EE" in name:
+            assert k["lds"] <= 40960, (name, k)
+        else:
+            assert k["lds"] <= 163840, (name, k)

@@ -70,7 +70,7 @@ def test_wave_parallel_std_sort_matches_libstdcxx(ops):
     rng = np.random.RandomState(0)
     arrays = []
     for trial in range(1500):
-        n = int(rng.choice([1, 2, 15, 16, 17, 18, 24, 31, 32, 33, 40, 48, 56, 63, 64, 65, 100, 127, 128, 129, 257, 400, 512]))
+        n = int(rng.choice([1, 2, 15, 16, 17, 18, 24, 31, 32, 33, 40, 48, 56, 63, 64, 65, 100, 127, 128, 129, 257, 300, 320, 321, 350, 384, 400, 512]))
         kind = trial % 6
         if kind == 0:
             k = np.ones(n)
@@ -92,14 +92,17 @@ def test_wave_parallel_std_sort_matches_libstdcxx(ops):
     lib, h = ops._handle(torch.device("cuda", 0))
     # bit 0: descending; bit 1: arrays of <= 64 elements go through the register-resident variant (one wave per array);
     # bit 2: the half-wave variant, two arrays of <= 32 elements side by side (longer ones are skipped);
-    # bit 3: the level-synchronous variant (every segment of a recursion level partitioned in the same pass)
-    for desc in (0, 1, 2, 3, 4, 5, 8, 9):
+    # bit 3: the level-synchronous variant (every segment of a recursion level partitioned in the same pass); bit 4: the same over an
+    # index array whose comparison looks the keys up (128-slot candidates; arrays beyond 128 keys are skipped)
+    for desc in (0, 1, 2, 3, 4, 5, 8, 9, 16, 17):
         out = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device="cuda")
         rc = lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr())
         assert rc == 0
         got = out.cpu().numpy()
         for a_i, k in enumerate(arrays):
             if (desc & 4) and len(k) > 32:
+                continue
+            if (desc & 16) and len(k) > 128:
                 continue
             exp = oracle.stdsort_perm(k, bool(desc & 1))
             assert np.array_equal(got[offs[a_i]:offs[a_i + 1]], exp), (a_i, len(k), desc)
