@@ -911,6 +911,38 @@ RLAP_HD void cand_sample(const Arrays& A, CT& C) {
     cand_recur(A, C);
 }
 
+// Picks that name target j among ksel[8w .. 8w+8) (positions below `limit` only): 0x80 in byte q of the result iff
+// ksel[8w+q] == j.  One 8-byte load and a handful of ALU operations instead of eight byte loads and compares -- the replay
+// and the slot phases ask this for every (candidate, target) pair.  (ksel is 8-byte aligned in every CandT.)
+RLAP_HD int popcount_u64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+RLAP_HD int clz_u64(uint64_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+RLAP_HD int ctz_u64(uint64_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long)x) - 1;
+#else
+    return __builtin_ctzll(x);
+#endif
+}
+RLAP_HD uint64_t ksel_matches(const uint8_t* ksel, int32_t w, int32_t j, int32_t limit) {
+    const uint64_t lo7 = 0x7F7F7F7F7F7F7F7Full;
+    const uint64_t x = reinterpret_cast<const uint64_t*>(ksel)[w] ^ (0x0101010101010101ull * (uint64_t)(uint8_t)j);
+    uint64_t y = ~(((x & lo7) + lo7) | x | lo7);          // 0x80 in every byte of x that is zero
+    const int32_t valid = limit - 8 * w;                   // bytes of this word that are positions below the limit
+    if (valid < 8) y &= valid <= 0 ? 0ull : ((1ull << (8 * valid)) - 1ull);
+    return y;
+}
 // Net PQ effect of candidate C on its target at position j, starting from key0
 // (valid while every intermediate key stays <= n, where each change moves the
 // vertex; otherwise *complex is set).  Returns the new key; *mv = op number of
@@ -923,7 +955,11 @@ RLAP_HD void cand_replay_pre(const Arrays& A, const CT& C, int32_t j, int* cnt, 
     if (A.o_v == OV_COARSEN) {
         if (j == C.koff) c = m - 1;
     } else {
-        for (int32_t q = 0; q < m - 1; ++q) if (C.ksel[q] == j) { ++c; li = q; }
+        // positions q < m-1 with ksel[q] == j, eight picks per load (ksel_matches)
+        for (int32_t w = 0; 8 * w < m - 1; ++w) {
+            const uint64_t y = ksel_matches(C.ksel, w, j, m - 1);
+            if (y) { c += popcount_u64(y); li = 8 * w + ((63 - clz_u64(y)) >> 3); }
+        }
     }
     *cnt = c; *last_inc = li;
 }

@@ -2881,9 +2881,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             if (me.i < P) {
                 const Cand& C = L.cand[me.i];
                 if (BC <= 64 && A.o_v == OV_COARSEN) { if (me.j == C.koff) pm = ((C.m >= 64 ? ~0ull : ((1ull << C.m) - 1ull)) & ~(1ull << C.koff)); }
-                else for (int32_t p = 0; p < C.m - 1; ++p) {
-                    const bool hit = (C.ksel[p] == me.j);
-                    if (BC <= 64 || p < 64) pm |= hit ? (1ull << (p & 63)) : 0ull; else pm_hi |= hit ? (1ull << (p & 63)) : 0ull;
+                else for (int32_t w = 0; 8 * w < C.m - 1; ++w) {
+                    for (uint64_t y = ksel_matches(C.ksel, w, me.j, C.m - 1); y; y &= y - 1) {
+                        const int32_t p = 8 * w + (ctz_u64(y) >> 3);
+                        if (BC <= 64 || p < 64) pm |= 1ull << (p & 63); else pm_hi |= 1ull << (p & 63);
+                    }
                 }
             }
             L.cont[tid].x = (int32_t)(uint32_t)pm; L.cont[tid].j = (int32_t)(uint32_t)(pm >> 32);
@@ -2961,15 +2963,26 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                             ++a;
                         }
                     } else {
-                    const bool co = A.o_v == OV_COARSEN;
-                    const int32_t plast = co ? C.m : C.m - 1;
-                    for (int32_t p = 0; p < plast; ++p) {
-                        if (co ? (p == C.koff) : (C.ksel[p] != j)) continue;
-                        int c = chunk_of(a);
-                        int32_t cs = chunk_start(c);
-                        if (a == cs) { A.e[cursor].nbr = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
-                        L.pslot[i * BCAP + p] = chunk + 1 + (a - cs);
-                        ++a;
+                    if (A.o_v == OV_COARSEN) {
+                        for (int32_t p = 0; p < C.m; ++p) {
+                            if (p == C.koff) continue;
+                            int c = chunk_of(a);
+                            int32_t cs = chunk_start(c);
+                            if (a == cs) { A.e[cursor].nbr = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
+                            L.pslot[i * BCAP + p] = chunk + 1 + (a - cs);
+                            ++a;
+                        }
+                    } else {
+                        for (int32_t w = 0; 8 * w < C.m - 1; ++w) {   // the picks that name this target, eight per load, ascending
+                            for (uint64_t y = ksel_matches(C.ksel, w, j, C.m - 1); y; y &= y - 1) {
+                                const int32_t p = 8 * w + (ctz_u64(y) >> 3);
+                                int c = chunk_of(a);
+                                int32_t cs = chunk_start(c);
+                                if (a == cs) { A.e[cursor].nbr = chunk; chunk = cursor; cursor += 1 + chunk_cap(c); }
+                                L.pslot[i * BCAP + p] = chunk + 1 + (a - cs);
+                                ++a;
+                            }
+                        }
                     }
                     }
                     A.vr[xk[k]].app_cnt = a; A.vr[xk[k]].app_chunk = chunk;
