@@ -1871,11 +1871,24 @@ __device__ __noinline__ void cand_prepare_wide(const Arrays& A, CandT<128>& C, i
     const int32_t nlive = popc64(h0) + popc64(h1);
     // ---- rank by id among the live entries (dead ones last); equal ids = multi-edges.  Key = (id, place in the traversal
     //      order): the network's order is the stable one, i.e. the insertion sort's ----
+    // A column without appended entries whose CSR segment is still in order (in-place twin rewrites can break it: every slot,
+    // live or dead, must lie strictly above its successor) is read in descending id: the rank is a count of the live entries behind.
+    bool clean = false;
+    if (C.acnt == 0 && ext <= 64) {   // (wave-uniform)
+        const int32_t nxt = __shfl_down(n0, 1);
+        clean = __ballot(a0 && (lane + 1 < ext) && !(n0 > nxt)) == 0ull;
+    }
+    int32_t r0, r1 = 0;
+    bool anydup = false;
+    if (clean) {
+        r0 = popc64(h0 & ~((2ull << lane) - 1ull));
+        if (lane == 63) r0 = 0;
+        WAVE_SYNC();   // (the raw entries stored by the caller: not read on this path, but the stores below must come after them)
+    } else {
     unsigned long long ik[2];
     ik[0] = ((unsigned long long)(live0 ? (uint32_t)n0 : 0x7FFFFFFFu) << 8) | (unsigned)lane;
     ik[1] = ((unsigned long long)(live1 ? (uint32_t)n1 : 0x7FFFFFFFu) << 8) | (unsigned)(64 + lane);
     wave_bitonic128(ik, lane, ext);   // (slots e >= ext hold nothing)
-    bool anydup;
     {
         unsigned long long pv0 = __shfl_up(ik[0], 1), pv1 = __shfl_up(ik[1], 1);
         const unsigned long long edge = __shfl(ik[0], 63);
@@ -1887,8 +1900,9 @@ __device__ __noinline__ void cand_prepare_wide(const Arrays& A, CandT<128>& C, i
     posmap[(int)(ik[0] & 0xFFull)] = (uint8_t)lane;
     posmap[(int)(ik[1] & 0xFFull)] = (uint8_t)(64 + lane);
     WAVE_SYNC();   // (also: the raw entries stored by the caller)
-    const int32_t r0 = posmap[lane], r1 = posmap[64 + lane];
+    r0 = posmap[lane]; r1 = posmap[64 + lane];
     WAVE_SYNC();
+    }
     int32_t rk0 = r0, rk1 = r1;
     bool merge = false;
     if (anydup) {
