@@ -1602,8 +1602,8 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
 // Batch kernel
 // ---------------------------------------------------------------------------
 // Two shapes of the workgroup: 1024 threads (4096 slots per round, ~156 KB LDS, one workgroup per CU) for a few large
-// graphs; 256 threads (1024 slots, ~50 KB, three workgroups per CU) when a batch holds more graphs than the device has
-// CUs -- small graphs give short rounds anyway and three of them hide each other's latency.
+// graphs; 256 threads (1024 slots, 39 KB and 128 VGPRs: four workgroups per CU) when a batch holds more graphs than the device has
+// CUs -- small graphs give short rounds anyway and four of them hide each other's latency.
 constexpr int PASSES = 4;     // (candidate, slot) pairs per thread: slots per round = 4 x threads
 
 struct CRec { int32_t x, i, j; };
