@@ -282,6 +282,28 @@ def test_wide_candidates_random_order(ops, monkeypatch, o_n, wide):
                 assert_same(b, a, f"killer star{n} hub@{first} {o_n} wide={wide}")
 
 
+def test_wide_candidates_batched(ops):
+    """128-slot candidates in a batched call of the 1024-thread shape (fewer graphs than CUs, dense graphs): every graph against
+    the oracle, graph g with seed + g."""
+    from rlap_amd import graphs
+    G = 40
+    eis, ns = [], []
+    for g in range(G):
+        n = 500 + 13 * g
+        eis.append(torch.from_numpy(ba_graph(n, 16 + g % 5, 70 + g))); ns.append(n)
+    big, node_ptr = graphs.batch_disjoint(eis, ns)
+    perms = [np.random.RandomState(g).permutation(n) for g, n in enumerate(ns)]
+    for o_n in ("asc", "random"):
+        sc, rp = ops.approximate_cholesky_batched(big.cuda(), None, node_ptr, [n // 2 for n in ns], "random", o_n,
+                                                  perm=torch.from_numpy(np.concatenate(perms)), seed=9)
+        sc = sc.cpu().numpy()
+        for g in range(G):
+            ref = oracle.approximate_cholesky(eis[g].numpy(), None, ns[g], ns[g] // 2, "random", o_n, perm=perms[g], shuffle_seed=9 + g)
+            got = sc[int(rp[g]):int(rp[g + 1])].copy()
+            got[:, :2] -= int(node_ptr[g])
+            assert_same(got, ref, f"batched wide graph {g} {o_n}")
+
+
 @pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
 def test_long_surviving_columns(ops, o_n):
     """Output pass: surviving columns beyond the 512-entry tiers (LDS record array, up to 8192 entries) and
