@@ -1063,15 +1063,34 @@ constexpr int HELP_MIN = 24;   // columns shorter than this keep the recurrence 
 // Wave 1 while wave 0 runs the single-vertex path: waits for the request, runs the recurrence over the ordered weights, reports.
 // (csum is recomputed here: the same left-to-right sum the eliminating wave forms for the cumulative weights.)
 template <int EC>
-__device__ __noinline__ void single_helper(ElimLdsT<EC>& L, int32_t* help) {
+__device__ __noinline__ void single_helper(ElimLdsT<EC>& L, double* big_newv, int32_t* help) {
     const int lane = lane_id();
     int f = 0;
     if (lane == 0) {
         int sp = 0;
-        while ((f = __hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 1 && f != 3 && ++sp < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        while ((f = __hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 1 && f != 3 && f != 4 && ++sp < (1 << 22)) __builtin_amdgcn_s_sleep(1);
     }
     f = __shfl(f, 0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (f == 4) {   // the long-column path (wave_eliminate_big): the ordered weights are in its newv[], rewritten in place
+        if (lane == 0) {
+            const int m = help[1];
+            double csum = 0;
+            for (int j = 0; j < m; ++j) csum += big_newv[j];
+            double wdeg = csum, colScale = 1;
+            for (int j = 0; j < m - 1; ++j) {
+                double w = big_newv[j] * colScale;
+                double f2 = w / wdeg;
+                double omf = 1 - f2;
+                big_newv[j] = f2 * omf * wdeg;
+                colScale = colScale * omf;
+                wdeg = wdeg * omf * omf;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&help[0], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
     if (f != 1) {
         if (lane == 0 && f == 3) __hip_atomic_store(&help[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return;
@@ -1434,7 +1453,7 @@ struct BigElimLdsT {
 
 template <int BIGE>
 __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, BigElimLdsT<BIGE>& L, const ColBuf& B, int32_t cap, int32_t v,
-                                                int32_t cp0, int32_t cp1, int32_t acnt, int32_t abase) {
+                                                int32_t cp0, int32_t cp1, int32_t acnt, int32_t abase, int32_t* help) {
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     if (cap > BIGE) cap = BIGE;
@@ -1525,26 +1544,39 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
     // ---- cumulative weights + the f / colScale / wdeg recurrences (:728-779), in LDS over the sort records ----
     double* cum = L.c.cum;
     double* newv = L.c.newv;
-    for (int j = lane; j < m; j += 64) newv[j] = B.a_val[j];
+    for (int j = lane; j < m; j += 64) { const double w = B.a_val[j]; newv[j] = w; cum[j] = w; }
     WAVE_SYNC();
+    // the new-weight recurrence runs on the workgroup's second wave (single_helper, request 4: in place over newv[]) while this
+    // one forms the cumulative weights (in place over cum[]), samples and hands out the slots; it is needed at the rewire
+    const bool helped = m >= HELP_MIN;
+    if (helped && lane == 0) {
+        help[1] = m;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&help[0], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#define BIG_HELP_FINISH() do { if (helped) { if (lane == 0) { int _sp = 0; while (__hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 && ++_sp < (1 << 22)) __builtin_amdgcn_s_sleep(1); \
+        __hip_atomic_store(&help[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); WAVE_SYNC(); } \
+        else if (lane == 0) __hip_atomic_store(&help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     if (lane == 0) {
         double csum = 0;
-        for (int j = 0; j < m; ++j) { csum += newv[j]; cum[j] = csum; }
-        double wdeg = csum, colScale = 1;
-        for (int j = 0; j < m - 1; ++j) {
-            double w = newv[j] * colScale;
-            double f = w / wdeg;
-            double omf = 1 - f;
-            newv[j] = f * omf * wdeg;
-            colScale = colScale * omf;
-            wdeg = wdeg * omf * omf;
+        for (int j = 0; j < m; ++j) { csum += cum[j]; cum[j] = csum; }
+        if (!helped) {
+            double wdeg = csum, colScale = 1;
+            for (int j = 0; j < m - 1; ++j) {
+                double w = newv[j] * colScale;
+                double f = w / wdeg;
+                double omf = 1 - f;
+                newv[j] = f * omf * wdeg;
+                colScale = colScale * omf;
+                wdeg = wdeg * omf * omf;
+            }
         }
     }
     WAVE_SYNC();
     const double csum = m > 0 ? cum[m - 1] : 0.0;
     const int64_t draws0 = G.n_draws;
     const int ndraw = m > 1 ? m - 1 : 0;
-    if (draws0 + ndraw > A.rng_len) { if (lane == 0) G.status = ST_RNG_OVERFLOW; WAVE_SYNC(); return true; }
+    if (draws0 + ndraw > A.rng_len) { BIG_HELP_FINISH(); if (lane == 0) G.status = ST_RNG_OVERFLOW; WAVE_SYNC(); return true; }
 
     // ---- sample k for every position but the last (:747-756) ----
     for (int j = lane; j < m - 1; j += 64) {
@@ -1555,6 +1587,8 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
     }
     WAVE_SYNC();
 
+    BIG_HELP_FINISH();   // (the new weights are in place from here on)
+#undef BIG_HELP_FINISH
     // ---- rewire (:766-776), 64 positions at a time in position order: lanes that drew the same target form a
     //      group whose first lane hands out the target's next slots in lane (= position) order ----
     int32_t status = 0;
@@ -2172,14 +2206,16 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 int32_t acnt = A2.vr[v0].app_cnt, abase = A2.vr[v0].app_chunk;
                 if ((cp1 - cp0) + acnt > EC1) {
                     ColBuf Bf = S2.colbuf(G.scr_base);
-                    const bool handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
-                    if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
-                    if (lane == 0) __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const bool handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase, s_help);
+                    if (!handled && lane == 0) {   // (a column the long-column path took has told the helper itself)
+                        serial_eliminate_call(A2, G, S2, v0, done + 1);
+                        __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 } else {
                     wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr, s_help);
                 }
             } else if (tid < 128) {
-                single_helper(sh.e, s_help);
+                single_helper(sh.e, sh.g.c.newv, s_help);
             }
             __syncthreads();
             if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
@@ -2846,15 +2882,17 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     bool handled = false;
                     if (OV == OV_RANDOM) {
                         ColBuf Bf = S2.colbuf(G.scr_base);
-                        handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase);
+                        handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase, s_help);
                     }
-                    if (!handled && lane == 0) serial_eliminate_call(A2, G, S2, v0, done + 1);
-                    if (lane == 0) __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (!handled && lane == 0) {
+                        serial_eliminate_call(A2, G, S2, v0, done + 1);
+                        __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 } else {
                     wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr, s_help);
                 }
             } else if (tid < 128) {
-                single_helper(sh.e, s_help);
+                single_helper(sh.e, sh.g.c.newv, s_help);
             }
             if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_anydep = 0; s_npatched = 0; }
             __syncthreads();
