@@ -46,6 +46,20 @@ with open(os.path.join(PROF, f"{rnd}_kernel_stats_bench_c3.csv"), "w") as f:
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         f.write(f"{k},{c},{t/1e6:.3f},{t/c/1e3:.1f},{100*t/tot:.3f}\n")
 
+# 1b. the same for the config-5 workload, when the round's script collected it (trace_c5/)
+hits_c5 = glob.glob(os.path.join(src, "trace_c5/**/*kernel_stats.csv"), recursive=True)
+if hits_c5:
+    agg5 = {}
+    for r in csv.DictReader(open(hits_c5[0])):
+        a = agg5.setdefault(short(r["Name"]), [0, 0])
+        a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
+    tot5 = sum(v[1] for v in agg5.values())
+    with open(os.path.join(PROF, f"{rnd}_kernel_stats_bench_c5.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c5 --steps 5 --warmup 2 --no-cpu-baseline (7 calls of the op: 1024 x BA(4096,8), o_v=random; measured at {os.environ.get('RLAP_COMMIT', '?')}; rocPRIM template names shortened)\n")
+        f.write("kernel,calls,total_ms,avg_us,percent\n")
+        for k, (c, t) in sorted(agg5.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{k},{c},{t/1e6:.3f},{t/c/1e3:.1f},{100*t/tot5:.3f}\n")
+
 
 # 2. PMC
 def load(path, counter):
