@@ -162,7 +162,7 @@ def main():
     c5 = args.workload == "c5"
     o_v = args.o_v or ("random" if c5 else "degree")
     o_n = args.o_n
-    ops.set_timing(True, dev)
+    ops.set_timing(True)
 
     if not c5:
         n, m = args.nodes, args.m

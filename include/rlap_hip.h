@@ -21,6 +21,7 @@
 #ifndef RLAP_HIP_H
 #define RLAP_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -46,7 +47,8 @@ enum {
     RLAP_E_OUT_OVERFLOW = 7,  /* out_cap_rows too small; *needed rows reported */
     RLAP_E_HIP = 8,
     RLAP_E_TOO_LARGE = 9,     /* nnz + growth pool exceeds int32 slot ids */
-    RLAP_E_INTERNAL = 10
+    RLAP_E_INTERNAL = 10,
+    RLAP_E_WORKSPACE = 11     /* caller-provided workspace / uniform table too small: rlap_workspace_needed() says how much */
 };
 
 typedef struct {
@@ -67,11 +69,29 @@ typedef struct {
     int64_t n_singles;    /* elimination: vertices that took the single-vertex path     */
 } rlap_stats;
 
-/* Lifetime.  A handle binds to the HIP device current at creation and owns a
- * grow-only device workspace and the cached MT19937-64 uniform table. */
+/* Lifetime.  A handle binds to the HIP device current at creation.  It owns a few KB of tables (allocated in
+ * rlap_create); every per-call buffer is carved from ONE workspace arena and the cached MT19937-64 uniform table is a
+ * second buffer -- the caller's (rlap_set_workspace) or, without one, the handle's own (one hipMalloc each, repeated only
+ * when a call is of a larger size class than any before it; never a hipFree/hipMalloc in a call that fits). */
 int rlap_create(rlap_handle* out);
 int rlap_destroy(rlap_handle h);
 int rlap_set_stream(rlap_handle h, void* hip_stream); /* hipStream_t; NULL = default */
+
+/* Workspace contract (SURVEY 8(b) "caller owns every buffer"; the reference's only allocation is the torch tensor of its
+ * result, py_api_binder.cc:42).
+ *   rlap_workspace_bytes : upper bound, for a fresh handle, of the arena bytes and of the uniform-table entries a call on
+ *                          E directed input entries, n_total vertices (summed over the G graphs of a batch) needs, whatever
+ *                          num_remove and the split of n_total over the graphs are.
+ *   rlap_workspace_query : the same for THIS handle (its growth factors rise after an RLAP_E_*_OVERFLOW retry).
+ *   rlap_set_workspace   : d_ws (256-byte aligned, ws_bytes) and d_rng (rng_entries doubles) are used by all later calls; the
+ *                          library then allocates and frees nothing.  NULL gives a buffer back to the handle.  The table is
+ *                          generated into d_rng by the first call that needs it (and again whenever d_rng changes).
+ *   A call that does not fit returns RLAP_E_WORKSPACE without touching the device; rlap_workspace_needed reports what it
+ *   wanted (the caller allocates that much and repeats the call). */
+int rlap_workspace_bytes(int64_t E, int64_t n_total, int64_t G, int symmetrize, size_t* ws_bytes, int64_t* rng_entries);
+int rlap_workspace_query(rlap_handle h, int64_t E, int64_t n_total, int64_t G, int symmetrize, size_t* ws_bytes, int64_t* rng_entries);
+int rlap_set_workspace(rlap_handle h, void* d_ws, size_t ws_bytes, double* d_rng, int64_t rng_entries);
+int rlap_workspace_needed(rlap_handle h, size_t* ws_bytes, int64_t* rng_entries);
 int rlap_set_timing(rlap_handle h, int enable);       /* fill rlap_stats.ms_* with HIP events */
 const char* rlap_status_string(int status);
 
@@ -140,6 +160,18 @@ int rlap_approx_chol_from_edges(rlap_handle h, const int64_t* d_src, const int64
  * PQ-log factor, length of the uniform table the kernels may use, entries of the output pass's long-column
  * scratch.  A call that runs into one of them repeats itself with the regular sizes (rlap_stats.n_retries). */
 int rlap_debug_set_limits(rlap_handle h, double pool_factor, double log_factor, int64_t rng_len, int64_t scratch_entries);
+
+/* Debug aid (also: environment RLAP_DEBUG_POISON=<byte> at rlap_create): before every attempt of the next calls the whole
+ * workspace arena, the caller's output buffer and the elimination kernel's LDS are filled with `byte` (0..255; negative = off),
+ * so that a kernel reading something it was never given reads that byte and not the previous call's (or the previous
+ * workgroup's) data -- a stale read changes the result deterministically instead of once in a thousand runs. */
+int rlap_debug_set_poison(rlap_handle h, int byte);
+
+/* Debug aid (also: environment RLAP_DEBUG_JITTER=<n> at rlap_create): behind every workgroup barrier of the elimination kernel
+ * a changing subset of the waves sleeps for n x 0.25 us (0 = off, at most 64).  A value that one wave reads behind a barrier while
+ * another wave already rewrites it -- a race that needs a wave to fall a microsecond behind and otherwise shows once in some
+ * thousand calls -- then shows in every call.  Results must not depend on it. */
+int rlap_debug_set_jitter(rlap_handle h, int quarter_us);
 
 /* First `count` uniforms of the sampling stream (default-seeded std::mt19937_64
  * through uniform_real_distribution<double>(0,1), preconditioner.cc:356-357)

@@ -17,7 +17,10 @@ EXPORTS = [
     "rlap_identity", "rlap_unpack_edge_info", "rlap_approx_chol", "rlap_approx_chol_batched",
     "rlap_rng_uniforms", "rlap_util_ba_graph", "rlap_debug_wave_sort",
     "rlap_approx_chol_from_edges", "rlap_debug_set_limits", "rlap_pack_rows", "rlap_unpack_rows",
+    "rlap_workspace_bytes", "rlap_workspace_query", "rlap_set_workspace", "rlap_workspace_needed", "rlap_debug_set_poison", "rlap_debug_set_jitter",
 ]
+
+E_WORKSPACE = 11   # RLAP_E_WORKSPACE
 
 
 class Stats(ctypes.Structure):
@@ -78,6 +81,19 @@ def load():
     lib.rlap_rng_uniforms.argtypes = [vp, i64, vp]
     lib.rlap_debug_wave_sort.restype = ci
     lib.rlap_debug_wave_sort.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]
+    sz = ctypes.c_size_t
+    lib.rlap_workspace_bytes.restype = ci
+    lib.rlap_workspace_bytes.argtypes = [i64, i64, i64, ci, ctypes.POINTER(sz), ctypes.POINTER(i64)]
+    lib.rlap_workspace_query.restype = ci
+    lib.rlap_workspace_query.argtypes = [vp, i64, i64, i64, ci, ctypes.POINTER(sz), ctypes.POINTER(i64)]
+    lib.rlap_set_workspace.restype = ci
+    lib.rlap_set_workspace.argtypes = [vp, vp, sz, vp, i64]
+    lib.rlap_workspace_needed.restype = ci
+    lib.rlap_workspace_needed.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(i64)]
+    lib.rlap_debug_set_jitter.restype = ci
+    lib.rlap_debug_set_jitter.argtypes = [vp, ci]
+    lib.rlap_debug_set_poison.restype = ci
+    lib.rlap_debug_set_poison.argtypes = [vp, ci]
     lib.rlap_util_ba_graph.restype = i64
     lib.rlap_util_ba_graph.argtypes = [i64, i64, u64, vp, vp]
     _lib = lib

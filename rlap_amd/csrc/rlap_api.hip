@@ -44,6 +44,20 @@ inline unsigned nblk(int64_t n, int bs) { return (unsigned)std::max<int64_t>(1, 
 
 }  // namespace
 
+// Every per-call buffer is carved out of ONE arena (256-byte aligned pieces, the layout is a function of the host-known sizes E, n, G
+// and the handle's growth factors).  The arena is either the caller's (rlap_set_workspace: torch's allocator in rlap_amd/ops.py -- the
+// reference lets torch allocate what the op needs, py_api_binder.cc:42) or the handle's own (one hipMalloc, grown only when a call needs
+// a larger size class than any before it).  The cached uniform table is a second, persistent buffer under the same rule.
+struct Carver {
+    char* base; size_t off;
+    template <class T> T* take(int64_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += sizeof(T) * (size_t)(count > 0 ? count : 0);
+        return p;
+    }
+};
+
 struct rlap_handle_s {
     int device = 0;
     int n_cu = 0;                 // compute units of `device`
@@ -54,19 +68,19 @@ struct rlap_handle_s {
     hipEvent_t ev[8];
     hipStream_t side[2] = {nullptr, nullptr};   // the output pass's independent tiers run side by side
     hipEvent_t fork_ev[3];
-    // setup
-    DevBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, deg, colptr, slot_col, permchk, genperm;
-    // graph state
-    DevBuf ent, vrec, ocur, oend, origpos, orig_order, gd_d, pool_top;
-    DevBuf bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, prof;
-    DevBuf skey0, skey1, sval0, sval1;
-    DevBuf rng;
+    // the arena: caller-provided (ext_ws) or owned
+    void* ext_ws = nullptr; size_t ext_ws_bytes = 0;
+    DevBuf own_ws;
+    size_t ws_needed = 0;         // bytes the last call wanted (reported with RLAP_E_WORKSPACE)
+    // the uniform table: caller-provided or owned; rng_len = entries generated so far in the current buffer
+    double* ext_rng = nullptr; int64_t ext_rng_cap = 0;
+    DevBuf own_rng;
+    double* rng_ptr = nullptr;
     int64_t rng_len = 0;
-    DevBuf eqtab;   // k_eq_tables, built with the first call
-    bool eqtab_built = false;
-    DevBuf scr_rec, scr_i32, scr_f64;
-    // output
-    DevBuf surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, out_ptr_d, sc_rec, sc_i32, sc_f64, biglist, biglists, hugelists, results;
+    int64_t rng_needed = 0;       // entries the last call wanted
+    DevBuf eqtab;   // k_eq_tables, allocated and built at rlap_create
+    DevBuf small;   // two 64-bit words for rlap_approx_chol_from_edges' num_nodes reduction (max id + 1, negative-id flag)
+    DevBuf prof;    // diagnostic phase profile (RLAP_PHASE_PROFILE=1), allocated at rlap_create
     // pinned host mirror of what a call reads back
     void* h_results = nullptr; size_t h_results_cap = 0;
     // growth factors kept across calls
@@ -78,6 +92,8 @@ struct rlap_handle_s {
     double dbg_pool = -1.0, dbg_log = -1.0; int64_t dbg_rng = -1, dbg_scr = -1;
     int64_t total_retries = 0;
     bool force_sort = false;      // the next attempt sorts the COO whatever order it is in (set when a skipped sort cannot be trusted)
+    int jitter = 0;               // RLAP_DEBUG_JITTER=<n>: waves of the elimination kernel sleep n x 0.25 us behind its barriers (a different set each time)
+    int poison = -1;              // RLAP_DEBUG_POISON=<byte>: the arena, the output buffer and the elimination kernel's LDS are filled with it before every attempt
 };
 
 namespace {
@@ -92,40 +108,71 @@ struct Scalars {
     unsigned long long live[LIVE_SLOTS * LIVE_STRIDE];   // live entries read by the output pass, partial sums
 };
 
+// The first `count` uniforms of the sampling stream (K10) in the handle's table.  The table lives in the caller's buffer
+// (rlap_set_rng_table) or in the handle's own; it is generated from the start whenever the buffer changes or must grow.
 int ensure_rng(rlap_handle h, int64_t count) {
-    if (count <= h->rng_len) return RLAP_OK;
-    int64_t want = std::max<int64_t>(count, 1 << 16);
-    ENSURE(h->rng, sizeof(double) * (size_t)want);
-    want = (int64_t)(h->rng.cap / sizeof(double));
-    hipLaunchKernelGGL(k_mt19937_64_table, dim3(1), dim3(320), 0, h->stream, h->rng.as<double>(), want);
+    h->rng_needed = std::max<int64_t>(count, 1 << 16);
+    if (h->rng_ptr && count <= h->rng_len) return RLAP_OK;
+    int64_t want = h->rng_needed;
+    double* buf = nullptr;
+    if (h->ext_rng) {
+        if (want > h->ext_rng_cap) return RLAP_E_WORKSPACE;
+        buf = h->ext_rng; want = h->ext_rng_cap;
+    } else {
+        ENSURE(h->own_rng, sizeof(double) * (size_t)want);
+        buf = h->own_rng.as<double>(); want = (int64_t)(h->own_rng.cap / sizeof(double));
+    }
+    hipLaunchKernelGGL(k_mt19937_64_table, dim3(1), dim3(320), 0, h->stream, buf, want);
     HIPCHK(hipGetLastError());
-    h->rng_len = want;
+    h->rng_ptr = buf; h->rng_len = want;
     return RLAP_OK;
 }
 
+// temporary storage of the rocPRIM calls: sized up front (queries with a null pointer touch nothing) and carved from the arena
+struct SortTmp { void* p; size_t bytes; };
+
 template <class K, class V>
-int sort_pairs(rlap_handle h, K* k_in, K* k_out, V* v_in, V* v_out, int64_t n, unsigned begin_bit, unsigned end_bit) {
+int sort_pairs(rlap_handle h, const SortTmp& T, K* k_in, K* k_out, V* v_in, V* v_out, int64_t n, unsigned begin_bit, unsigned end_bit) {
     size_t bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, k_in, k_out, v_in, v_out, (size_t)n, begin_bit, end_bit, h->stream));
-    ENSURE(h->sorttmp, bytes);
-    bytes = h->sorttmp.cap;
-    HIPCHK(rocprim::radix_sort_pairs(h->sorttmp.p, bytes, k_in, k_out, v_in, v_out, (size_t)n, begin_bit, end_bit, h->stream));
+    if (bytes > T.bytes) return RLAP_E_INTERNAL;   // (sort_tmp_bytes asks the same questions up front)
+    bytes = T.bytes;
+    HIPCHK(rocprim::radix_sort_pairs(T.p, bytes, k_in, k_out, v_in, v_out, (size_t)n, begin_bit, end_bit, h->stream));
     return RLAP_OK;
 }
 
 template <class In, class Out>
-int excl_scan(rlap_handle h, In* in, Out* out, int64_t n) {
+int excl_scan(rlap_handle h, const SortTmp& T, In* in, Out* out, int64_t n) {
     size_t bytes = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, bytes, in, out, (Out)0, (size_t)n, rocprim::plus<Out>(), h->stream));
-    ENSURE(h->sorttmp, bytes);
-    bytes = h->sorttmp.cap;
-    HIPCHK(rocprim::exclusive_scan(h->sorttmp.p, bytes, in, out, (Out)0, (size_t)n, rocprim::plus<Out>(), h->stream));
+    if (bytes > T.bytes) return RLAP_E_INTERNAL;
+    bytes = T.bytes;
+    HIPCHK(rocprim::exclusive_scan(T.p, bytes, in, out, (Out)0, (size_t)n, rocprim::plus<Out>(), h->stream));
+    return RLAP_OK;
+}
+
+inline unsigned bits_for(uint64_t maxval) { unsigned b = 1; while (b < 64 && (maxval >> b) != 0) ++b; return b; }
+
+// largest temporary any rocPRIM call of a call with these sizes asks for (the very calls run_once makes, asked with null storage)
+int sort_tmp_bytes(int64_t Eeff, int64_t N, int64_t G, int64_t S, size_t* out) {
+    size_t mx = 256, b = 0;
+    hipStream_t s0 = nullptr;
+    const unsigned kbits = bits_for((uint64_t)(N > 1 ? N - 1 : 1)), gbits = bits_for((uint64_t)(G > 0 ? G - 1 : 0));
+    if (Eeff > 0) {
+        b = 0; HIPCHK(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)Eeff, 0u, std::min(64u, 2 * kbits + 1), s0)); mx = std::max(mx, b);
+        rocprim::counting_iterator<uint32_t> iota(0u);
+        b = 0; HIPCHK(rocprim::radix_sort_pairs(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, iota, (uint32_t*)nullptr, (size_t)Eeff, 0u, std::min(32u, kbits + 1), s0)); mx = std::max(mx, b);
+        b = 0; HIPCHK(rocprim::exclusive_scan(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(Eeff + 1), rocprim::plus<int32_t>(), s0)); mx = std::max(mx, b);
+    }
+    const size_t Nn = (size_t)std::max<int64_t>(N, 1);
+    b = 0; HIPCHK(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, Nn, 0u, 32u + gbits, s0)); mx = std::max(mx, b);
+    b = 0; HIPCHK(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, Nn, 0u, 64u, s0)); mx = std::max(mx, b);
+    b = 0; HIPCHK(rocprim::exclusive_scan(nullptr, b, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(S + 1), rocprim::plus<int64_t>(), s0)); mx = std::max(mx, b);
+    *out = mx;
     return RLAP_OK;
 }
 
 constexpr int64_t SORT_SKIP_MIN = 1 << 21;   // directed entries from which the order of the input is looked at before sorting it
-
-inline unsigned bits_for(uint64_t maxval) { unsigned b = 1; while (b < 64 && (maxval >> b) != 0) ++b; return b; }
 
 struct Fills {
     FillJobs J; int64_t maxcount = 0;
@@ -140,20 +187,95 @@ struct Fills {
 };
 
 // keyed random permutation of each graph's local ids, drawn on the device (stands in for the
-// std::shuffle(random_device) of preconditioner.cc:594-596 when the caller injects no node_id vector)
-__global__ void k_perm_keys(const int32_t* __restrict__ vgraph, const GraphDesc* __restrict__ gd, int32_t N, uint64_t seed,
+// std::shuffle(random_device) of preconditioner.cc:594-596 when the caller injects no node_id vector).
+// Graph g of a batch is keyed by seed + g like the neighbour order (rlap_core.h): a batched or sharded call draws what
+// single-graph calls with seed + g draw, whatever the sharding.  64 hash bits: no ties to break at any graph size.
+__global__ void k_perm_keys(const int32_t* __restrict__ vgraph, const GraphDesc* __restrict__ gd, int32_t N, uint64_t seed, int gbits,
                             uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int32_t g = vgraph[i];
     const uint32_t local = (uint32_t)(i - gd[g].vbase);
-    // (graph, 32 hash bits) -- ties between equal hashes are broken by the stable radix sort (input order)
-    keys[i] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)(mix64(seed + (uint64_t)g * 0x9E3779B97F4A7C15ull ^ mix64(local)) >> 32);
+    const uint64_t hk = mix64(mix64((seed + (uint64_t)g) ^ 0x7065726D5F6B6579ull) ^ mix64(local));
+    // one graph: the whole hash; a batch: the graph number on top of 64 - gbits hash bits (one 64-bit sort either way)
+    keys[i] = gbits == 0 ? hk : (((uint64_t)(uint32_t)g << (64 - gbits)) | (hk >> gbits));
     vals[i] = local;
 }
 __global__ void k_widen_u32(const uint32_t* __restrict__ in, int32_t N, int64_t* __restrict__ out) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) out[i] = (int64_t)in[i];
+}
+
+
+// Host-known sizes of one call (upper bounds; what only the device knows -- nnz, row counts -- never sizes a buffer).
+struct Sizes {
+    int64_t G, N, Eeff, slot_cap, bucket_total, log_total, scr_total, S, scr_budget;
+    size_t sort_tmp, res_bytes;
+    bool want_genperm;
+};
+struct WBuf { void* p = nullptr; template <class T> T* as() const { return reinterpret_cast<T*>(p); } };
+struct WS {
+    WBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, colptr, slot_col, permchk, genperm, ent, vrec, ocur, oend, origpos, orig_order, gd_d, pool_top, bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, skey0, skey1, sval0, sval1, scr_rec, scr_i32, scr_f64, surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, sc_rec, sc_i32, sc_f64, biglist, hugelists, results;
+};
+// the arena's layout: run once with a null base to learn the size, once more to place the buffers
+size_t carve(Carver& C, const Sizes& z, WS& W) {
+    const int64_t G = z.G, N = z.N, S = z.S, Ealloc = std::max<int64_t>(z.Eeff, 1), BT = z.bucket_total;
+    W.scal.p = C.take<Scalars>(1);
+    W.results.p = C.take<char>((int64_t)z.res_bytes);
+    W.node_ptr_d.p = C.take<int64_t>(G + 1);
+    W.gd_d.p = C.take<GraphDesc>(G);
+    W.surv_base_d.p = C.take<int64_t>(G + 1);
+    W.pool_top.p = C.take<int32_t>(1);
+    W.bs_pool_top.p = C.take<int32_t>(1);
+    W.vgraph.p = C.take<int32_t>(N);
+    W.keys0.p = C.take<uint64_t>(Ealloc); W.keys1.p = C.take<uint64_t>(Ealloc);
+    W.idx0.p = C.take<uint32_t>(Ealloc); W.idx1.p = C.take<uint32_t>(Ealloc);
+    W.head.p = C.take<int32_t>(Ealloc + 1); W.pos.p = C.take<int32_t>(Ealloc + 1);
+    W.sorttmp.p = C.take<char>((int64_t)z.sort_tmp);
+    W.ent.p = C.take<Slot>(z.slot_cap);
+    W.slot_col.p = C.take<int32_t>(Ealloc);
+    W.colptr.p = C.take<int32_t>(N + 1);
+    W.vrec.p = C.take<VRec>(N);
+    W.origpos.p = C.take<int32_t>(N);
+    W.ocur.p = C.take<int32_t>(BT); W.oend.p = C.take<int32_t>(BT);
+    W.bs_cnt.p = C.take<int32_t>(BT); W.bs_alloc.p = C.take<int32_t>(BT); W.bs_dir.p = C.take<int32_t>(BT * BDIR);
+    W.bs_v.p = C.take<int32_t>(z.log_total); W.bs_id.p = C.take<int32_t>(z.log_total);
+    W.batch_pos.p = C.take<int32_t>(N);
+    W.skey0.p = C.take<uint64_t>(N); W.skey1.p = C.take<uint64_t>(N); W.sval0.p = C.take<uint32_t>(N); W.sval1.p = C.take<uint32_t>(N);
+    W.orig_order.p = C.take<int32_t>(N);
+    W.permchk.p = C.take<int32_t>(N);
+    W.genperm.p = C.take<int64_t>(z.want_genperm ? N : 0);
+    W.scr_rec.p = C.take<SRec>(z.scr_total); W.scr_i32.p = C.take<int32_t>(10 * z.scr_total); W.scr_f64.p = C.take<double>(4 * z.scr_total);
+    W.ext.p = C.take<int32_t>(S + 1); W.cnt.p = C.take<int32_t>(S + 1); W.tmp_off.p = C.take<int64_t>(S + 1); W.row_off.p = C.take<int64_t>(S + 1);
+    W.tmp_nbr.p = C.take<int32_t>(z.slot_cap); W.tmp_val.p = C.take<double>(z.slot_cap);   // staged rows: at most one per slot in use
+    W.sc_rec.p = C.take<SRec>(z.scr_budget); W.sc_i32.p = C.take<int32_t>(7 * z.scr_budget); W.sc_f64.p = C.take<double>(2 * z.scr_budget);
+    W.biglist.p = C.take<int32_t>(8 * (S + 1));
+    W.hugelists.p = C.take<uint16_t>((int64_t)NHUGE * 2 * (HUGECAP + 2));
+    return (C.off + 255) & ~(size_t)255;
+}
+
+// sizes of a call on (E directed input entries, N vertices, G graphs, S surviving vertices) under the handle's growth factors
+int call_sizes(const rlap_handle h, int64_t Eeff, int64_t N, int64_t G, int64_t bucket_total, int64_t S, bool want_genperm, Sizes* z) {
+    const double pool_factor = h->dbg_pool >= 0 ? h->dbg_pool : h->pool_factor;
+    const double log_factor = h->dbg_log >= 0 ? h->dbg_log : h->log_factor;
+    const int64_t nnz_ub = Eeff;
+    const int64_t pool = (int64_t)(pool_factor * nnz_ub) + (h->dbg_pool >= 0 ? 0 : 16 * N + 1024) + G * (G <= 512 ? (int64_t)POOL_GRAB_BIG : (int64_t)POOL_GRAB_SMALL);
+    z->G = G; z->N = N; z->Eeff = Eeff; z->S = S; z->bucket_total = bucket_total;
+    z->slot_cap = nnz_ub + pool;
+    if (z->slot_cap >= ((int64_t)1 << 31) - 64) return RLAP_E_TOO_LARGE;
+    z->log_total = (int64_t)(log_factor * nnz_ub) + (h->dbg_log >= 0 ? 64 : (int64_t)BCH0 * bucket_total + 64 * G);
+    z->scr_total = nnz_ub / 2 + 8 * G + 8;
+    if (bucket_total * BDIR >= ((int64_t)1 << 40) || bucket_total >= ((int64_t)1 << 31) || z->log_total >= ((int64_t)1 << 31)) return RLAP_E_TOO_LARGE;
+    z->scr_budget = h->dbg_scr >= 0 ? h->dbg_scr : h->scr_budget;
+    z->res_bytes = sizeof(CallResults) + 8 * (size_t)(G + 1);
+    z->want_genperm = want_genperm;
+    return sort_tmp_bytes(Eeff, N, G, S, &z->sort_tmp);
+}
+
+// uniforms a call may draw: a graph rarely draws more than its own directed entry count; an overflow doubles the table
+int64_t rng_guess(const rlap_handle h, int64_t Eeff, int64_t G) {
+    int64_t guess = (G == 1) ? Eeff + 1024 : std::min<int64_t>(Eeff + 1024, 4 * (Eeff / G) + 65536);
+    return std::max<int64_t>(std::max(guess, h->rng_min), 1 << 16);
 }
 
 struct Call {
@@ -189,11 +311,6 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
 
     // ---------------- sizes (host-known upper bounds) ----------------
     const int64_t nnz_ub = Eeff;
-    const double pool_factor = h->dbg_pool >= 0 ? h->dbg_pool : h->pool_factor;
-    const double log_factor = h->dbg_log >= 0 ? h->dbg_log : h->log_factor;
-    const int64_t pool = (int64_t)(pool_factor * nnz_ub) + (h->dbg_pool >= 0 ? 0 : 16 * N + 1024) + G * (G <= 512 ? (int64_t)POOL_GRAB_BIG : (int64_t)POOL_GRAB_SMALL);
-    const int64_t slot_cap = nnz_ub + pool;
-    if (slot_cap >= ((int64_t)1 << 31) - 64) return RLAP_E_TOO_LARGE;
     std::vector<GraphDesc> gd((size_t)G);
     int64_t bucket_total = 0, nelim_total = 0;
     std::vector<int64_t> surv_base((size_t)G + 1, 0);
@@ -208,60 +325,46 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         nelim_total += ne;
         surv_base[g + 1] = surv_base[g] + (n - ne);
     }
-    const int64_t log_total = (int64_t)(log_factor * nnz_ub) + (h->dbg_log >= 0 ? 64 : (int64_t)BCH0 * bucket_total + 64 * G);
-    const int64_t scr_total = nnz_ub / 2 + 8 * G + 8;
-    if (bucket_total * BDIR >= ((int64_t)1 << 40) || bucket_total >= ((int64_t)1 << 31) || log_total >= ((int64_t)1 << 31)) return RLAP_E_TOO_LARGE;
     const int64_t S = surv_base[G];
     st.n_eliminated = nelim_total;
-    const int64_t scr_budget = h->dbg_scr >= 0 ? h->dbg_scr : h->scr_budget;
+    Sizes z;
+    { int rc = call_sizes(h, Eeff, N, G, bucket_total, S, c.o_v == OV_RANDOM && !c.d_perm, &z); if (rc) return rc; }
+    const int64_t slot_cap = z.slot_cap, log_total = z.log_total, scr_total = z.scr_total, scr_budget = z.scr_budget;
+    const size_t res_bytes = z.res_bytes;
 
-    // ---------------- workspace ----------------
-    ENSURE(h->node_ptr_d, sizeof(int64_t) * (G + 1));
-    ENSURE(h->vgraph, sizeof(int32_t) * N);
-    ENSURE(h->scal, sizeof(Scalars));
-    const int64_t Ealloc = std::max<int64_t>(Eeff, 1);
-    ENSURE(h->keys0, 8 * Ealloc); ENSURE(h->keys1, 8 * Ealloc);
-    ENSURE(h->idx0, 4 * Ealloc); ENSURE(h->idx1, 4 * Ealloc);
-    ENSURE(h->head, 4 * (Ealloc + 1)); ENSURE(h->pos, 4 * (Ealloc + 1));
-    ENSURE(h->ent, sizeof(Slot) * slot_cap);
-    ENSURE(h->slot_col, 4 * Ealloc);
-    ENSURE(h->colptr, 4 * (N + 1));
-    ENSURE(h->gd_d, sizeof(GraphDesc) * G);
-    ENSURE(h->vrec, sizeof(VRec) * N);
-    ENSURE(h->origpos, 4 * N);
-    ENSURE(h->ocur, 4 * bucket_total); ENSURE(h->oend, 4 * bucket_total);
-    ENSURE(h->bs_cnt, 4 * bucket_total); ENSURE(h->bs_alloc, 4 * bucket_total); ENSURE(h->bs_dir, 4 * bucket_total * BDIR);
-    ENSURE(h->bs_v, 4 * log_total); ENSURE(h->bs_id, 4 * log_total); ENSURE(h->bs_pool_top, 4);
-    ENSURE(h->batch_pos, 4 * N);
-    ENSURE(h->skey0, 8 * N); ENSURE(h->skey1, 8 * N); ENSURE(h->sval0, 4 * N); ENSURE(h->sval1, 4 * N);
-    ENSURE(h->orig_order, 4 * N);
-    ENSURE(h->scr_rec, sizeof(SRec) * scr_total); ENSURE(h->scr_i32, 4 * 10 * scr_total); ENSURE(h->scr_f64, 8 * 4 * scr_total);
-    ENSURE(h->pool_top, 4);
-    ENSURE(h->surv_base_d, 8 * (G + 1));
-    ENSURE(h->ext, 4 * (S + 1)); ENSURE(h->cnt, 4 * (S + 1)); ENSURE(h->tmp_off, 8 * (S + 1)); ENSURE(h->row_off, 8 * (S + 1));
-    ENSURE(h->tmp_nbr, 4 * slot_cap); ENSURE(h->tmp_val, 8 * slot_cap);   // staged rows: at most one per slot in use
-    ENSURE(h->sc_rec, sizeof(SRec) * scr_budget); ENSURE(h->sc_i32, 4 * 7 * scr_budget); ENSURE(h->sc_f64, 8 * 2 * scr_budget);
-    ENSURE(h->biglist, 4 * 8 * (S + 1));
-    ENSURE(h->hugelists, (size_t)NHUGE * 2 * (HUGECAP + 2) * sizeof(uint16_t));
-    ENSURE(h->out_ptr_d, 8 * (G + 1));
-    const size_t res_bytes = sizeof(CallResults) + 8 * (size_t)(G + 1);
-    ENSURE(h->results, res_bytes);
+    // ---------------- workspace: one arena, no allocation unless this call is of a larger size class than any before ----------------
+    WS W;
+    {
+        Carver dry{nullptr, 0};
+        const size_t need = carve(dry, z, W);
+        h->ws_needed = need;
+        char* base = nullptr;
+        if (h->ext_ws) {
+            if (need > h->ext_ws_bytes) return RLAP_E_WORKSPACE;   // the caller allocates rlap_workspace_needed() bytes and calls again
+            base = static_cast<char*>(h->ext_ws);
+        } else {
+            ENSURE(h->own_ws, need);
+            base = h->own_ws.as<char>();
+        }
+        Carver real{base, 0};
+        carve(real, z, W);
+        if (h->poison >= 0) {   // debug: whatever a kernel reads without having been given it is this byte, not the previous call's data
+            HIPCHK(hipMemsetAsync(base, h->poison, need, s));
+            if (c.d_out && c.out_cap > 0) HIPCHK(hipMemsetAsync(c.d_out, h->poison, sizeof(double) * 3 * (size_t)c.out_cap, s));
+        }
+    }
     if (res_bytes > h->h_results_cap) {
         if (h->h_results) (void)hipHostFree(h->h_results);
         h->h_results = nullptr; h->h_results_cap = 0;
-        HIPCHK(hipHostMalloc(&h->h_results, res_bytes + 1024, hipHostMallocDefault));
-        h->h_results_cap = res_bytes + 1024;
+        HIPCHK(hipHostMalloc(&h->h_results, res_bytes + 65536, hipHostMallocDefault));
+        h->h_results_cap = res_bytes + 65536;
     }
-    {
-        // uniforms: a graph rarely draws more than its own directed entry count; an overflow doubles the table
-        int64_t guess = (G == 1) ? nnz_ub + 1024 : std::min<int64_t>(nnz_ub + 1024, 4 * (nnz_ub / G) + 65536);
-        guess = std::max(guess, h->rng_min);
-        int rc = ensure_rng(h, std::max<int64_t>(guess, h->rng_len)); if (rc) return rc;
-    }
+    { int rc = ensure_rng(h, rng_guess(h, Eeff, G)); if (rc) return rc; }
+    const SortTmp ST{W.sorttmp.p, z.sort_tmp};
     // (test hook: the kernels are told the table is shorter than it is)
     const int64_t rng_len_eff = h->dbg_rng >= 0 ? std::min<int64_t>(h->rng_len, h->dbg_rng) : h->rng_len;
 
-    Scalars* SC = h->scal.as<Scalars>();
+    Scalars* SC = W.scal.as<Scalars>();
     int32_t* flags = SC->flags;
     double* acc = SC->acc;
     unsigned long long* counters = SC->counters;   // [0] sc scratch top
@@ -269,30 +372,30 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     int32_t* nnz_p = &SC->nnz;
 
     // ---------------- setup: COO -> CSR ----------------
-    HIPCHK(hipMemcpyAsync(h->node_ptr_d.p, c.h_node_ptr, sizeof(int64_t) * (G + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->gd_d.p, gd.data(), sizeof(GraphDesc) * G, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->surv_base_d.p, surv_base.data(), 8 * (G + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.node_ptr_d.p, c.h_node_ptr, sizeof(int64_t) * (G + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.gd_d.p, gd.data(), sizeof(GraphDesc) * G, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.surv_base_d.p, surv_base.data(), 8 * (G + 1), hipMemcpyHostToDevice, s));
     {
         Fills F;
-        F.add(h->scal.p, sizeof(Scalars) / 4, 0);
-        F.add(h->bs_cnt.p, bucket_total, 0); F.add(h->bs_alloc.p, bucket_total, 0);
-        F.add(h->ocur.p, bucket_total, 0); F.add(h->oend.p, bucket_total, 0);
-        F.add(h->bs_pool_top.p, 1, 0);
-        F.add(h->batch_pos.p, N, -1);
-        F.add(h->ext.as<int32_t>() + S, 1, 0); F.add(h->cnt.as<int32_t>() + S, 1, 0);
-        if (G == 1) F.add(h->vgraph.p, N, 0);
+        F.add(W.scal.p, sizeof(Scalars) / 4, 0);
+        F.add(W.bs_cnt.p, bucket_total, 0); F.add(W.bs_alloc.p, bucket_total, 0);
+        F.add(W.ocur.p, bucket_total, 0); F.add(W.oend.p, bucket_total, 0);
+        F.add(W.bs_pool_top.p, 1, 0);
+        F.add(W.batch_pos.p, N, -1);
+        F.add(W.ext.as<int32_t>() + S, 1, 0); F.add(W.cnt.as<int32_t>() + S, 1, 0);
+        if (G == 1) F.add(W.vgraph.p, N, 0);
         F.launch(s);
     }
-    if (G > 1) hipLaunchKernelGGL(k_vertex_graph, dim3(nblk(N, 256)), dim3(256), 0, s, h->node_ptr_d.as<int64_t>(), (int)G, h->vgraph.as<int32_t>(), N);
+    if (G > 1) hipLaunchKernelGGL(k_vertex_graph, dim3(nblk(N, 256)), dim3(256), 0, s, W.node_ptr_d.as<int64_t>(), (int)G, W.vgraph.as<int32_t>(), N);
 
     const int kbits = (int)bits_for((uint64_t)(N > 1 ? N - 1 : 1));
     bool swapped = false;   // the input was in (row, col) order and is read transposed (same matrix when it is exactly symmetric)
-    uint64_t* keys_sorted = h->keys1.as<uint64_t>();
-    uint32_t* idx_sorted = h->idx1.as<uint32_t>();
-    uint32_t* rowid = h->idx0.as<uint32_t>();   // dense row ids of the slots (key of the twin sort); a buffer the COO sort has left free
+    uint64_t* keys_sorted = W.keys1.as<uint64_t>();
+    uint32_t* idx_sorted = W.idx1.as<uint32_t>();
+    uint32_t* rowid = W.idx0.as<uint32_t>();   // dense row ids of the slots (key of the twin sort); a buffer the COO sort has left free
     if (Eeff > 0) {
-        hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_row, c.d_col, c.d_w, E, N, G > 1 ? h->vgraph.as<int32_t>() : (const int32_t*)nullptr,
-                           c.symmetrize, kbits, h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), flags);
+        hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_row, c.d_col, c.d_w, E, N, G > 1 ? W.vgraph.as<int32_t>() : (const int32_t*)nullptr,
+                           c.symmetrize, kbits, W.keys0.as<uint64_t>(), W.idx0.as<uint32_t>(), flags);
         // Large inputs: one early look at the order flags (the call's only other host synchronisation) -- a COO that is sorted by
         // (col, row) needs no sort, one sorted by (row, col) (PyG coalesce) is read transposed and needs none either; exact symmetry,
         // which makes the transposed reading the same matrix, is verified with the twins (else the call is repeated with the sort).
@@ -305,108 +408,101 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
             HIPCHK(hipStreamSynchronize(s));
             if (!fl[FLAG_UNSORTED_CR]) skip_sort = true;
             else if (!fl[FLAG_UNSORTED_RC] && !fl[FLAG_RANGE]) {
-                hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_col, c.d_row, c.d_w, E, N, G > 1 ? h->vgraph.as<int32_t>() : (const int32_t*)nullptr,
-                                   0, kbits, h->keys0.as<uint64_t>(), h->idx0.as<uint32_t>(), flags);
+                hipLaunchKernelGGL(k_edge_keys, dim3(nblk(Eeff, 256)), dim3(256), 0, s, c.d_col, c.d_row, c.d_w, E, N, G > 1 ? W.vgraph.as<int32_t>() : (const int32_t*)nullptr,
+                                   0, kbits, W.keys0.as<uint64_t>(), W.idx0.as<uint32_t>(), flags);
                 skip_sort = true; swapped = true;
             }
         }
         st.reserved = skip_sort ? (swapped ? 2 : 1) : 0;
         if (skip_sort) {
-            keys_sorted = h->keys0.as<uint64_t>(); idx_sorted = h->idx0.as<uint32_t>();
-            rowid = h->idx1.as<uint32_t>();
+            keys_sorted = W.keys0.as<uint64_t>(); idx_sorted = W.idx0.as<uint32_t>();
+            rowid = W.idx1.as<uint32_t>();
         } else {
             // keys are (col << kbits | row) with ids < N, or all ones for dropped entries (bit 2 * kbits makes these sort last)
-            int rc = sort_pairs(h, h->keys0.as<uint64_t>(), h->keys1.as<uint64_t>(), h->idx0.as<uint32_t>(), h->idx1.as<uint32_t>(), Eeff, 0,
+            int rc = sort_pairs(h, ST, W.keys0.as<uint64_t>(), W.keys1.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), Eeff, 0,
                                 (unsigned)std::min(64, 2 * kbits + 1));
             if (rc) return rc;
         }
         { Fills F2; F2.add(rowid, Eeff, (int32_t)N); F2.launch(s); }   // dense row-id array: slots beyond nnz hold N (sorts last)
-        hipLaunchKernelGGL(k_heads, dim3(nblk(Eeff + 1, 256)), dim3(256), 0, s, keys_sorted, Eeff, h->head.as<int32_t>());
-        int rc = excl_scan(h, h->head.as<int32_t>(), h->pos.as<int32_t>(), Eeff + 1);
+        hipLaunchKernelGGL(k_heads, dim3(nblk(Eeff + 1, 256)), dim3(256), 0, s, keys_sorted, Eeff, W.head.as<int32_t>());
+        int rc = excl_scan(h, ST, W.head.as<int32_t>(), W.pos.as<int32_t>(), Eeff + 1);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(nnz_p, h->pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, keys_sorted, idx_sorted, h->head.as<int32_t>(),
-                           h->pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, kbits, h->ent.as<Slot>(), h->slot_col.as<int32_t>(),
+        HIPCHK(hipMemcpyAsync(nnz_p, W.pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, keys_sorted, idx_sorted, W.head.as<int32_t>(),
+                           W.pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, kbits, W.ent.as<Slot>(), W.slot_col.as<int32_t>(),
                            reinterpret_cast<int32_t*>(rowid));
     }
-    hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, h->slot_col.as<int32_t>(), nnz_p, (int32_t)N, h->colptr.as<int32_t>());
+    hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, W.slot_col.as<int32_t>(), nnz_p, (int32_t)N, W.colptr.as<int32_t>());
     if (Eeff > 0) {
         // twins: stable sort of the slots by row id (keys0 is free again: sorted keys in its first half, the slot order T in its second)
-        uint32_t* skeys = h->keys0.as<uint32_t>();
+        uint32_t* skeys = W.keys0.as<uint32_t>();
         uint32_t* T = skeys + Eeff;
-        size_t bytes = 0;
         rocprim::counting_iterator<uint32_t> iota(0u);
+        size_t bytes = 0;
         HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, rowid, skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
-        ENSURE(h->sorttmp, bytes);
-        bytes = h->sorttmp.cap;
-        HIPCHK(rocprim::radix_sort_pairs(h->sorttmp.p, bytes, rowid, skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
-        hipLaunchKernelGGL(k_twin_sorted, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(), T, nnz_p, acc);
-        hipLaunchKernelGGL(k_twin_store, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, h->ent.as<Slot>(), T, nnz_p);
+        if (bytes > ST.bytes) return RLAP_E_INTERNAL;
+        bytes = ST.bytes;
+        HIPCHK(rocprim::radix_sort_pairs(ST.p, bytes, rowid, skeys, iota, T, (size_t)Eeff, 0u, (unsigned)std::min(32, kbits + 1), s));
+        hipLaunchKernelGGL(k_twin_sorted, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, W.ent.as<Slot>(), T, nnz_p, acc);
+        hipLaunchKernelGGL(k_twin_store, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, W.ent.as<Slot>(), T, nnz_p);
     }
-    HIPCHK(hipMemcpyAsync(h->pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(W.pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
     // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)
-    hipLaunchKernelGGL(k_gd_scratch, dim3(1), dim3(256), 0, s, h->colptr.as<int32_t>(), h->node_ptr_d.as<int64_t>(), (int32_t)G, h->gd_d.as<GraphDesc>());
+    hipLaunchKernelGGL(k_gd_scratch, dim3(1), dim3(256), 0, s, W.colptr.as<int32_t>(), W.node_ptr_d.as<int64_t>(), (int32_t)G, W.gd_d.as<GraphDesc>());
 
     // ---------------- PQ init ----------------
     const unsigned gbits = bits_for((uint64_t)(G > 0 ? G - 1 : 0));
-    hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, h->colptr.as<int32_t>(), h->vgraph.as<int32_t>(), (int32_t)N, h->vrec.as<VRec>(),
-                       h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
+    hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, W.colptr.as<int32_t>(), W.vgraph.as<int32_t>(), (int32_t)N, W.vrec.as<VRec>(),
+                       W.skey0.as<uint64_t>(), W.sval0.as<uint32_t>());
     {
         // key = graph << 32 | degree: only the bits that can be set take part in the sort
-        int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 32 + gbits);
+        int rc = sort_pairs(h, ST, W.skey0.as<uint64_t>(), W.skey1.as<uint64_t>(), W.sval0.as<uint32_t>(), W.sval1.as<uint32_t>(), N, 0, 32 + gbits);
         if (rc) return rc;
     }
-    HIPCHK(hipMemcpyAsync(h->orig_order.p, h->sval1.p, 4 * N, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, h->orig_order.as<uint32_t>(), h->vrec.as<VRec>(), h->vgraph.as<int32_t>(),
-                       h->gd_d.as<GraphDesc>(), (int32_t)N, h->ocur.as<int32_t>(), h->oend.as<int32_t>(), h->origpos.as<int32_t>());
+    HIPCHK(hipMemcpyAsync(W.orig_order.p, W.sval1.p, 4 * N, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, W.orig_order.as<uint32_t>(), W.vrec.as<VRec>(), W.vgraph.as<int32_t>(),
+                       W.gd_d.as<GraphDesc>(), (int32_t)N, W.ocur.as<int32_t>(), W.oend.as<int32_t>(), W.origpos.as<int32_t>());
 
     // ---------------- o_v = random: the node_id vector ----------------
     const int64_t* d_perm = c.d_perm;
     if (c.o_v == OV_RANDOM) {
         if (!d_perm) {
-            ENSURE(h->genperm, 8 * N);
-            hipLaunchKernelGGL(k_perm_keys, dim3(nblk(N, 256)), dim3(256), 0, s, h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N, c.seed,
-                               h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
-            int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 32 + gbits);
+            hipLaunchKernelGGL(k_perm_keys, dim3(nblk(N, 256)), dim3(256), 0, s, W.vgraph.as<int32_t>(), W.gd_d.as<GraphDesc>(), (int32_t)N, c.seed,
+                               G > 1 ? (int)gbits : 0, W.skey0.as<uint64_t>(), W.sval0.as<uint32_t>());
+            int rc = sort_pairs(h, ST, W.skey0.as<uint64_t>(), W.skey1.as<uint64_t>(), W.sval0.as<uint32_t>(), W.sval1.as<uint32_t>(), N, 0, 64);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_widen_u32, dim3(nblk(N, 256)), dim3(256), 0, s, h->sval1.as<uint32_t>(), (int32_t)N, h->genperm.as<int64_t>());
-            d_perm = h->genperm.as<int64_t>();
+            hipLaunchKernelGGL(k_widen_u32, dim3(nblk(N, 256)), dim3(256), 0, s, W.sval1.as<uint32_t>(), (int32_t)N, W.genperm.as<int64_t>());
+            d_perm = W.genperm.as<int64_t>();
         } else {
-            ENSURE(h->permchk, 4 * N);
-            HIPCHK(hipMemsetAsync(h->permchk.p, 0, 4 * N, s));
-            hipLaunchKernelGGL(k_perm_check, dim3(nblk(N, 256)), dim3(256), 0, s, d_perm, h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N,
-                               h->permchk.as<int32_t>(), flags);
+            HIPCHK(hipMemsetAsync(W.permchk.p, 0, 4 * N, s));
+            hipLaunchKernelGGL(k_perm_check, dim3(nblk(N, 256)), dim3(256), 0, s, d_perm, W.vgraph.as<int32_t>(), W.gd_d.as<GraphDesc>(), (int32_t)N,
+                               W.permchk.as<int32_t>(), flags);
         }
     }
 
     Arrays A;
-    A.colptr = h->colptr.as<int32_t>();
-    A.e = h->ent.as<Slot>();
-    A.slot_cap = (int32_t)slot_cap; A.pool_top = h->pool_top.as<int32_t>();
-    A.vr = h->vrec.as<VRec>();
-    A.ocur = h->ocur.as<int32_t>(); A.oend = h->oend.as<int32_t>();
-    A.orig_order = h->orig_order.as<int32_t>();
-    A.bs_cnt = h->bs_cnt.as<int32_t>(); A.bs_alloc = h->bs_alloc.as<int32_t>(); A.bs_dir = h->bs_dir.as<int32_t>();
-    A.bs_v = h->bs_v.as<int32_t>(); A.bs_id = h->bs_id.as<int32_t>();
-    A.bs_pool_top = h->bs_pool_top.as<int32_t>(); A.bs_pool_cap = (int32_t)log_total;
-    A.rng = h->rng.as<double>(); A.rng_len = rng_len_eff;
+    A.colptr = W.colptr.as<int32_t>();
+    A.e = W.ent.as<Slot>();
+    A.slot_cap = (int32_t)slot_cap; A.pool_top = W.pool_top.as<int32_t>();
+    A.vr = W.vrec.as<VRec>();
+    A.ocur = W.ocur.as<int32_t>(); A.oend = W.oend.as<int32_t>();
+    A.orig_order = W.orig_order.as<int32_t>();
+    A.bs_cnt = W.bs_cnt.as<int32_t>(); A.bs_alloc = W.bs_alloc.as<int32_t>(); A.bs_dir = W.bs_dir.as<int32_t>();
+    A.bs_v = W.bs_v.as<int32_t>(); A.bs_id = W.bs_id.as<int32_t>();
+    A.bs_pool_top = W.bs_pool_top.as<int32_t>(); A.bs_pool_cap = (int32_t)log_total;
+    A.rng = h->rng_ptr; A.rng_len = rng_len_eff;
     A.perm = d_perm; A.o_v = c.o_v; A.o_n = c.o_n; A.shuffle_seed = c.seed;
     ElimScratch ES;
-    ES.rec = h->scr_rec.as<SRec>(); ES.i32 = h->scr_i32.as<int32_t>(); ES.f64 = h->scr_f64.as<double>(); ES.cap = scr_total;
-    if (!h->eqtab_built) {
-        ENSURE(h->eqtab, EQTAB_BYTES);
-        launch_eq_tables(s, h->eqtab.as<uint8_t>());
-        HIPCHK(hipGetLastError());
-        h->eqtab_built = true;
-    }
+    ES.rec = W.scr_rec.as<SRec>(); ES.i32 = W.scr_i32.as<int32_t>(); ES.f64 = W.scr_f64.as<double>(); ES.cap = scr_total;
     ES.eqtab = h->eqtab.as<uint8_t>();
     ES.prof = nullptr;
     const char* prof_env = std::getenv("RLAP_PHASE_PROFILE");   // diagnostic only: per-phase clock sums of graph 0
-    if (prof_env && prof_env[0] == '1') {
-        ENSURE(h->prof, 8 * 40);
+    if (prof_env && prof_env[0] == '1' && h->prof.p) {
         HIPCHK(hipMemsetAsync(h->prof.p, 0, 8 * 40, s));
         ES.prof = h->prof.as<long long>();
     }
+    ES.poison = h->poison;
+    ES.jitter = h->jitter;
 
     if (h->timing) HIPCHK(hipEventRecord(h->ev[1], s));
     // ---------------- elimination ----------------
@@ -414,29 +510,29 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     // sizes: no read-back).  Measured (ms per call, 64 -> 128 slots): BA(1M,10) 2950 -> 2180, BA(169343,7) 260 -> 248, BA(4096,8)
     // 10.2 -> 9.2; BA(20000,5) 23.0 -> 23.4 and sparser graphs lose (their rounds fill 64 candidates and get only 32)
     const bool wide = c.o_v == OV_RANDOM && nnz_ub >= 12 * N && N >= 512;
-    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, h->n_cu, s, A, h->gd_d.as<GraphDesc>(), ES, h->batch_pos.as<int32_t>(), flags, acc, wide);
+    launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, h->n_cu, s, A, W.gd_d.as<GraphDesc>(), ES, W.batch_pos.as<int32_t>(), flags, acc, wide);
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
 
     // ---------------- output ----------------
     uint32_t* order = nullptr;
     if (c.o_v == OV_RANDOM) {
-        hipLaunchKernelGGL(k_sc_perm_order, dim3(nblk(N, 256)), dim3(256), 0, s, d_perm, h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(),
-                           h->surv_base_d.as<int64_t>(), (int32_t)N, h->sval1.as<uint32_t>());
-        order = h->sval1.as<uint32_t>();
+        hipLaunchKernelGGL(k_sc_perm_order, dim3(nblk(N, 256)), dim3(256), 0, s, d_perm, W.vgraph.as<int32_t>(), W.gd_d.as<GraphDesc>(),
+                           W.surv_base_d.as<int64_t>(), (int32_t)N, W.sval1.as<uint32_t>());
+        order = W.sval1.as<uint32_t>();
     } else {
-        hipLaunchKernelGGL(k_sc_keys, dim3(nblk(N, 256)), dim3(256), 0, s, h->vrec.as<VRec>(), h->origpos.as<int32_t>(),
-                           h->vgraph.as<int32_t>(), h->gd_d.as<GraphDesc>(), (int32_t)N, h->skey0.as<uint64_t>(), h->sval0.as<uint32_t>());
+        hipLaunchKernelGGL(k_sc_keys, dim3(nblk(N, 256)), dim3(256), 0, s, W.vrec.as<VRec>(), W.origpos.as<int32_t>(),
+                           W.vgraph.as<int32_t>(), W.gd_d.as<GraphDesc>(), (int32_t)N, W.skey0.as<uint64_t>(), W.sval0.as<uint32_t>());
         // key = bucket << 32 | order, all ones for eliminated vertices
-        int rc = sort_pairs(h, h->skey0.as<uint64_t>(), h->skey1.as<uint64_t>(), h->sval0.as<uint32_t>(), h->sval1.as<uint32_t>(), N, 0, 64);
+        int rc = sort_pairs(h, ST, W.skey0.as<uint64_t>(), W.skey1.as<uint64_t>(), W.sval0.as<uint32_t>(), W.sval1.as<uint32_t>(), N, 0, 64);
         if (rc) return rc;
-        order = h->sval1.as<uint32_t>();
+        order = W.sval1.as<uint32_t>();
     }
     if (S > 0)
-        hipLaunchKernelGGL(k_sc_ext, dim3(nblk(S, 256)), dim3(256), 0, s, order, h->colptr.as<int32_t>(), h->vrec.as<VRec>(), (int32_t)S, h->ext.as<int32_t>());
-    { int rc = excl_scan(h, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), S + 1); if (rc) return rc; }
+        hipLaunchKernelGGL(k_sc_ext, dim3(nblk(S, 256)), dim3(256), 0, s, order, W.colptr.as<int32_t>(), W.vrec.as<VRec>(), (int32_t)S, flags, acc, W.ext.as<int32_t>());
+    { int rc = excl_scan(h, ST, W.ext.as<int32_t>(), W.tmp_off.as<int64_t>(), S + 1); if (rc) return rc; }
     ScScratch SS;
-    SS.rec = h->sc_rec.as<SRec>(); SS.i32 = h->sc_i32.as<int32_t>(); SS.f64 = h->sc_f64.as<double>(); SS.cap = scr_budget; SS.top = counters + 0; SS.flags = flags;
+    SS.rec = W.sc_rec.as<SRec>(); SS.i32 = W.sc_i32.as<int32_t>(); SS.f64 = W.sc_f64.as<double>(); SS.cap = scr_budget; SS.top = counters + 0; SS.flags = flags;
     if (h->timing) HIPCHK(hipEventRecord(h->ev[3], s));
     if (S > 0) {
         int32_t* tiercounts = reinterpret_cast<int32_t*>(counters + 4);   // 8 ints: tiers 0..7
@@ -449,29 +545,29 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         ScLaunch X;
         X.main = s; X.side[0] = h->side[0]; X.side[1] = h->side[1];
         for (int q = 0; q < 3; ++q) X.ev[q] = h->fork_ev[q];
-        launch_sc_merge(X, A, h->gd_d.as<GraphDesc>(), h->vgraph.as<int32_t>(), order, h->ext.as<int32_t>(), h->tmp_off.as<int64_t>(), (int32_t)S,
-                        h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), h->cnt.as<int32_t>(), SS, live, h->biglist.as<int32_t>(), tiercounts,
-                        h->biglists.as<uint16_t>(), h->hugelists.as<uint16_t>());
+        launch_sc_merge(X, A, W.gd_d.as<GraphDesc>(), W.vgraph.as<int32_t>(), order, W.ext.as<int32_t>(), W.tmp_off.as<int64_t>(), (int32_t)S,
+                        W.tmp_nbr.as<int32_t>(), W.tmp_val.as<double>(), W.cnt.as<int32_t>(), SS, live, W.biglist.as<int32_t>(), tiercounts,
+                        W.hugelists.as<uint16_t>());
         HIPCHK(hipGetLastError());
     }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[4], s));
-    { int rc = excl_scan(h, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), S + 1); if (rc) return rc; }
+    { int rc = excl_scan(h, ST, W.cnt.as<int32_t>(), W.row_off.as<int64_t>(), S + 1); if (rc) return rc; }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[5], s));
     if (S > 0 && c.out_cap > 0) {
         const int64_t rows_ub = std::min<int64_t>(c.out_cap, slot_cap);
         unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows_ub + 255) / 256, 256 * 8));
-        hipLaunchKernelGGL(k_sc_compact, dim3(grid), dim3(256), 0, s, order, h->cnt.as<int32_t>(), h->row_off.as<int64_t>(), h->tmp_off.as<int64_t>(),
-                           h->tmp_nbr.as<int32_t>(), h->tmp_val.as<double>(), (int32_t)S, c.d_out, c.out_cap);
+        hipLaunchKernelGGL(k_sc_compact, dim3(grid), dim3(256), 0, s, order, W.cnt.as<int32_t>(), W.row_off.as<int64_t>(), W.tmp_off.as<int64_t>(),
+                           W.tmp_nbr.as<int32_t>(), W.tmp_val.as<double>(), (int32_t)S, c.d_out, c.out_cap);
         HIPCHK(hipGetLastError());
     }
     if (h->timing) HIPCHK(hipEventRecord(h->ev[6], s));
     // ---------------- the one read-back ----------------
-    CallResults* res_d = h->results.as<CallResults>();
+    CallResults* res_d = W.results.as<CallResults>();
     int64_t* out_ptr_d = reinterpret_cast<int64_t*>(res_d + 1);
-    hipLaunchKernelGGL(k_graph_rows, dim3(nblk(G + 1, 256)), dim3(256), 0, s, h->surv_base_d.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)G, out_ptr_d);
-    hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, s, flags, acc, nnz_p, counters, live, h->tmp_off.as<int64_t>(), h->row_off.as<int64_t>(), (int32_t)S,
-                       h->gd_d.as<GraphDesc>(), (int32_t)G, h->pool_top.as<int32_t>(), h->bs_pool_top.as<int32_t>(), res_d);
-    HIPCHK(hipMemcpyAsync(h->h_results, h->results.p, res_bytes, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_graph_rows, dim3(nblk(G + 1, 256)), dim3(256), 0, s, W.surv_base_d.as<int64_t>(), W.row_off.as<int64_t>(), (int32_t)G, out_ptr_d);
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(256), 0, s, flags, acc, nnz_p, counters, live, W.tmp_off.as<int64_t>(), W.row_off.as<int64_t>(), (int32_t)S,
+                       W.gd_d.as<GraphDesc>(), (int32_t)G, W.pool_top.as<int32_t>(), W.bs_pool_top.as<int32_t>(), res_d);
+    HIPCHK(hipMemcpyAsync(h->h_results, W.results.p, res_bytes, hipMemcpyDeviceToHost, s));
     if (h->timing) HIPCHK(hipEventRecord(h->ev[7], s));
     HIPCHK(hipStreamSynchronize(s));
     const CallResults& R = *reinterpret_cast<const CallResults*>(h->h_results);
@@ -564,24 +660,78 @@ int rlap_create(rlap_handle* out) {
     for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
     for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& st : h->side) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // everything a call needs besides its arena and the uniform table is allocated here, once: the equal-key permutation tables
+    // (built on the null stream, finished before rlap_create returns), the pinned read-back block, the diagnostic profile
+    ENSURE(h->small, 256);
+    ENSURE(h->eqtab, EQTAB_BYTES);
+    launch_eq_tables(nullptr, h->eqtab.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipHostMalloc(&h->h_results, 1 << 17, hipHostMallocDefault));
+    h->h_results_cap = 1 << 17;
+    if (const char* e = std::getenv("RLAP_PHASE_PROFILE")) { if (e[0] == '1') ENSURE(h->prof, 8 * 40); }
+    if (const char* e = std::getenv("RLAP_DEBUG_POISON")) { if (e[0]) h->poison = std::atoi(e) & 0xFF; }
+    if (const char* e = std::getenv("RLAP_DEBUG_JITTER")) { if (e[0]) h->jitter = std::max(0, std::min(64, std::atoi(e))); }
     *out = h;
     return RLAP_OK;
 }
 
 int rlap_destroy(rlap_handle h) {
     if (!h) return RLAP_OK;
-    DevBuf* bufs[] = {&h->node_ptr_d, &h->vgraph, &h->scal, &h->keys0, &h->keys1, &h->idx0, &h->idx1, &h->head, &h->pos, &h->sorttmp,
-                      &h->deg, &h->colptr, &h->slot_col, &h->permchk, &h->genperm, &h->ent, &h->vrec,
-                      &h->ocur, &h->oend, &h->origpos, &h->orig_order, &h->bs_cnt, &h->bs_alloc, &h->bs_dir, &h->bs_v, &h->bs_id, &h->bs_pool_top, &h->batch_pos, &h->prof, &h->gd_d, &h->pool_top, &h->skey0,
-                      &h->skey1, &h->sval0, &h->sval1, &h->rng, &h->eqtab, &h->scr_rec, &h->scr_i32, &h->scr_f64, &h->surv_base_d, &h->ext, &h->tmp_off,
-                      &h->tmp_nbr, &h->tmp_val, &h->cnt, &h->row_off, &h->out_ptr_d, &h->sc_rec, &h->sc_i32, &h->sc_f64, &h->biglist, &h->biglists, &h->hugelists, &h->results};
     DeviceGuard dg(h->device);
     if (h->h_results) (void)hipHostFree(h->h_results);
-    for (DevBuf* b : bufs) b->release();
+    h->own_ws.release(); h->own_rng.release(); h->eqtab.release(); h->prof.release(); h->small.release();
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     for (auto& e : h->fork_ev) (void)hipEventDestroy(e);
     for (auto& st : h->side) if (st) (void)hipStreamDestroy(st);
     delete h;
+    return RLAP_OK;
+}
+
+// ---- workspace contract ("caller owns every buffer"; the reference lets torch allocate, py_api_binder.cc:42) ----
+static int ws_query(const rlap_handle h, int64_t E, int64_t n_total, int64_t G, int symmetrize, size_t* ws_bytes, int64_t* rng_entries) {
+    if (E < 0 || n_total < 0 || G < 1) return RLAP_E_BAD_ARG;
+    const int64_t Eeff = symmetrize ? 2 * E : E;
+    if (n_total >= (int64_t)1 << 30 || Eeff >= (int64_t)1 << 31 || G >= (int64_t)1 << 30) return RLAP_E_TOO_LARGE;
+    rlap_handle_s defaults;   // (growth factors of a fresh handle when none is given)
+    const rlap_handle hh = h ? h : &defaults;
+    Sizes z;
+    // bounds that hold for every split of n_total over G graphs and every num_remove: 2n+1 buckets per graph, S <= n_total
+    int rc = call_sizes(hh, Eeff, n_total, G, 2 * n_total + G, n_total, true, &z);
+    if (rc) return rc;
+    WS W; Carver dry{nullptr, 0};
+    *ws_bytes = carve(dry, z, W);
+    *rng_entries = rng_guess(hh, Eeff, G);
+    return RLAP_OK;
+}
+
+int rlap_workspace_bytes(int64_t E, int64_t n_total, int64_t G, int symmetrize, size_t* ws_bytes, int64_t* rng_entries) {
+    if (!ws_bytes || !rng_entries) return RLAP_E_BAD_ARG;
+    return ws_query(nullptr, E, n_total, G, symmetrize, ws_bytes, rng_entries);
+}
+
+int rlap_workspace_query(rlap_handle h, int64_t E, int64_t n_total, int64_t G, int symmetrize, size_t* ws_bytes, int64_t* rng_entries) {
+    if (!h || !ws_bytes || !rng_entries) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return ws_query(h, E, n_total, G, symmetrize, ws_bytes, rng_entries);
+}
+
+int rlap_set_workspace(rlap_handle h, void* d_ws, size_t ws_bytes, double* d_rng, int64_t rng_entries) {
+    if (!h || (d_ws && (reinterpret_cast<uintptr_t>(d_ws) & 255)) || rng_entries < 0) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    DeviceGuard dg(h->device);
+    h->ext_ws = d_ws; h->ext_ws_bytes = d_ws ? ws_bytes : 0;
+    if (d_ws) h->own_ws.release();
+    if (d_rng != h->ext_rng || rng_entries != h->ext_rng_cap || (!d_rng && h->rng_ptr != h->own_rng.as<double>())) { h->rng_ptr = nullptr; h->rng_len = 0; }   // a table in another buffer is generated anew
+    h->ext_rng = d_rng; h->ext_rng_cap = d_rng ? rng_entries : 0;
+    if (d_rng) h->own_rng.release();
+    return RLAP_OK;
+}
+
+int rlap_workspace_needed(rlap_handle h, size_t* ws_bytes, int64_t* rng_entries) {
+    if (!h || !ws_bytes || !rng_entries) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    *ws_bytes = h->ws_needed; *rng_entries = h->rng_needed;
     return RLAP_OK;
 }
 
@@ -609,6 +759,7 @@ const char* rlap_status_string(int status) {
         case RLAP_E_OUT_OVERFLOW: return "output buffer too small";
         case RLAP_E_HIP: return "HIP runtime error";
         case RLAP_E_TOO_LARGE: return "problem exceeds int32 slot ids";
+        case RLAP_E_WORKSPACE: return "caller-provided workspace too small (see rlap_workspace_needed)";
         default: return "internal error";
     }
 }
@@ -685,16 +836,16 @@ int rlap_approx_chol_from_edges(rlap_handle h, const int64_t* d_src, const int64
         // num_nodes = edge_index.max() + 1 (augmentor_benchmarks.py:77): one reduction + one 8-byte read-back
         std::lock_guard<std::mutex> lock(h->mu);
         DeviceGuard dg(h->device);
-        unsigned long long mx = 0;
+        unsigned long long mx[2] = {0ull, 0ull};   // max id + 1, any id negative
         if (E > 0) {
-            ENSURE(h->scal, sizeof(Scalars));
-            unsigned long long* d_mx = &h->scal.as<Scalars>()->maxid;
-            HIPCHK(hipMemsetAsync(d_mx, 0, 8, h->stream));
+            unsigned long long* d_mx = h->small.as<unsigned long long>();
+            HIPCHK(hipMemsetAsync(d_mx, 0, 16, h->stream));
             hipLaunchKernelGGL(k_max_id, dim3((unsigned)std::min<int64_t>((E + 255) / 256, 1024)), dim3(256), 0, h->stream, d_src, d_dst, E, d_mx);
-            HIPCHK(hipMemcpyAsync(&mx, d_mx, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(mx, d_mx, 16, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
-        n = (int64_t)mx;
+        if (mx[1]) return RLAP_E_INDEX_RANGE;   // a negative id is out of range for every num_nodes (an explicit n reports the same)
+        n = (int64_t)mx[0];
     }
     if (t < 0) t = (int64_t)(remove_frac * (double)n);   // int(frac * num_nodes), augmentor_benchmarks.py:78
     if (h_num_nodes) *h_num_nodes = n;
@@ -714,13 +865,27 @@ int rlap_debug_set_limits(rlap_handle h, double pool_factor, double log_factor, 
     return RLAP_OK;
 }
 
+int rlap_debug_set_poison(rlap_handle h, int byte) {
+    if (!h) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->poison = byte < 0 ? -1 : (byte & 0xFF);
+    return RLAP_OK;
+}
+
+int rlap_debug_set_jitter(rlap_handle h, int quarter_us) {
+    if (!h) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->jitter = std::max(0, std::min(64, quarter_us));
+    return RLAP_OK;
+}
+
 int rlap_rng_uniforms(rlap_handle h, int64_t count, double* d_out) {
     if (!h || count < 0) return RLAP_E_BAD_ARG;
     std::lock_guard<std::mutex> lock(h->mu);
     DeviceGuard dg(h->device);
     int rc = ensure_rng(h, count);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(d_out, h->rng.p, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d_out, h->rng_ptr, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return RLAP_OK;
 }

@@ -51,6 +51,8 @@ struct ElimScratch {
     int64_t cap;    // total entries over all graphs
     const uint8_t* eqtab;   // k_eq_tables (per handle)
     long long* prof; // optional diagnostic build only: per-phase cycle sums of graph 0 (nullptr in production)
+    int32_t poison;  // debug (RLAP_DEBUG_POISON): >= 0 -> the workgroup's LDS is filled with this byte before anything else
+    int32_t jitter;  // debug (RLAP_DEBUG_JITTER): > 0 -> waves sleep behind the elimination kernel's barriers (schedule perturbation)
     __host__ __device__ ColBuf colbuf(int64_t base) const {
         ColBuf B;
         B.rec = rec + base;
@@ -112,7 +114,7 @@ __global__ void k_sc_keys(const VRec* vr, const int32_t* origpos, const int32_t*
                           int32_t N, uint64_t* skey, uint32_t* sval);
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,
                                 uint32_t* order);
-__global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const VRec* vr, int32_t S, int32_t* ext);
+__global__ void k_sc_ext(const uint32_t* order, const int32_t* colptr, const VRec* vr, int32_t S, const int32_t* in_flags, const double* in_acc, int32_t* ext);
 constexpr unsigned NHUGE = 32;   // workgroups of k_sc_merge_huge
 struct ScLaunch { hipStream_t main; hipStream_t side[2]; hipEvent_t ev[3]; };   // side streams may be null: everything on `main`
 template <int NW>
@@ -121,7 +123,7 @@ __global__ void k_sc_merge_mw(Arrays A, const GraphDesc* gd, const int32_t* vgra
                               unsigned long long* live_total, int32_t lcap, int32_t qcap);
 void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
-                     unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* biglists, uint16_t* hugelists);
+                     unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* hugelists);
 __global__ void k_debug_wave_sort(const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out);
 __global__ void k_sc_merge_big(Arrays A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext, const int64_t* tmp_off, const int32_t* list, const int32_t* count,
                                int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, unsigned long long* live_total, uint16_t* lists, int32_t lcap);

@@ -167,9 +167,11 @@ __global__ void k_edge_keys(const int64_t* __restrict__ row, const int64_t* __re
 __global__ void k_max_id(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t E, unsigned long long* __restrict__ out) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     long long m = -1;
-    for (; p < E; p += (int64_t)gridDim.x * blockDim.x) { long long r = row[p], c = col[p]; m = r > m ? r : m; m = c > m ? c : m; }
+    bool neg = false;
+    for (; p < E; p += (int64_t)gridDim.x * blockDim.x) { long long r = row[p], c = col[p]; m = r > m ? r : m; m = c > m ? c : m; neg |= (r < 0) | (c < 0); }
     for (int off = 32; off > 0; off >>= 1) { long long o = __shfl_down(m, off); m = o > m ? o : m; }
     if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(out, (unsigned long long)(m + 1));
+    if (neg) out[1] = 1ull;   // a negative id: out of range whatever num_nodes is
 }
 
 // several small fills in one launch (per-call state that used to take a dozen memsets)
@@ -1058,6 +1060,8 @@ __device__ __forceinline__ void new_weights(const double* a_val, double* newv, i
     }
 }
 
+constexpr int SPIN_LIMIT = 1 << 26;   // s_sleep(1) rounds a wave waits for another one of its workgroup before it gives up with ST_INTERNAL (about 2 s: the
+                                      // helper wave also sits out the sequential fall-back of a very long column, tens of milliseconds)
 constexpr int HELP_MIN = 24;   // columns shorter than this keep the recurrence on the eliminating wave (the hand-over costs about a microsecond)
 
 // Wave 1 while wave 0 runs the single-vertex path: waits for the request, runs the recurrence over the ordered weights, reports.
@@ -1068,7 +1072,8 @@ __device__ __noinline__ void single_helper(ElimLdsT<EC>& L, double* big_newv, in
     int f = 0;
     if (lane == 0) {
         int sp = 0;
-        while ((f = __hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 1 && f != 3 && f != 4 && ++sp < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+        while ((f = __hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 1 && f != 3 && f != 4 && ++sp < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+        if (sp >= SPIN_LIMIT) help[2] = 1;   // gave up: the workgroup reports ST_INTERNAL (a request posted later would never be answered)
     }
     f = __shfl(f, 0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1257,7 +1262,9 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(&help[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-#define HELP_FINISH() do { if (helped) { if (lane == 0) { int _sp = 0; while (__hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 && ++_sp < (1 << 22)) __builtin_amdgcn_s_sleep(1); \
+    // (a wait that runs out is an internal error, never a result: the new weights would be read unfinished)
+#define HELP_FINISH() do { if (helped) { if (lane == 0) { int _sp = 0; while (__hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 && ++_sp < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1); \
+        if (_sp >= SPIN_LIMIT) G.status = ST_INTERNAL; \
         __hip_atomic_store(&help[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); WAVE_SYNC(); } \
         else if (lane == 0) __hip_atomic_store(&help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     if (lane == 0) {
@@ -1554,7 +1561,8 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(&help[0], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-#define BIG_HELP_FINISH() do { if (helped) { if (lane == 0) { int _sp = 0; while (__hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 && ++_sp < (1 << 22)) __builtin_amdgcn_s_sleep(1); \
+#define BIG_HELP_FINISH() do { if (helped) { if (lane == 0) { int _sp = 0; while (__hip_atomic_load(&help[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 2 && ++_sp < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1); \
+        if (_sp >= SPIN_LIMIT) G.status = ST_INTERNAL; \
         __hip_atomic_store(&help[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); WAVE_SYNC(); } \
         else if (lane == 0) __hip_atomic_store(&help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
     if (lane == 0) {
@@ -2102,6 +2110,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                                                            int32_t* __restrict__ batch_pos, const int32_t* __restrict__ in_flags,
                                                            const double* __restrict__ in_acc) {
     constexpr int NT = NTT;            // threads per workgroup
+    // Workgroup barrier.  Debug (RLAP_DEBUG_JITTER=<n>, S.jitter): behind every barrier some waves -- a different set each time -- sleep
+    // for n x 0.25 us, so that a value read behind a barrier while another wave already rewrites it (the push-id race of round 2) shows
+    // in every run instead of once in some thousand.  Off: one scalar compare per barrier.
+    uint32_t jit_ctr = 0;
+#define BSYNC() do { __syncthreads(); if (S.jitter > 0) { ++jit_ctr; if (((((uint32_t)threadIdx.x >> 6) * 2654435761u + jit_ctr * 40503u) >> 7 & 3u) == 0u) \
+        for (int _q = 0; _q < S.jitter; ++_q) __builtin_amdgcn_s_sleep(8); } } while (0)
     constexpr int NWAVE = NT / 64;
     constexpr int SLOTS = PASSES * NT; // candidates x slots per round
     constexpr int MCAP = NT;           // PQ moves per round
@@ -2126,7 +2140,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     A.shuffle_seed = A_in.shuffle_seed + (uint64_t)blockIdx.x;   // graph g of a batch: seed + g, ids local to the graph (rlap_core.h)
     __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
-    __shared__ int32_t s_help[2];      // hand-over between the eliminating wave and its helper (single_helper)
+    __shared__ int32_t s_help[3];      // hand-over between the eliminating wave and its helper (single_helper); [2]: the helper gave up waiting
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end, s_anydep, s_npatched;
     constexpr int32_t POOL_GRAB = NT >= 1024 ? POOL_GRAB_BIG : POOL_GRAB_SMALL;   // slots reserved at a time for the round's appends
     // std::sort's permutation of n = 17..BC all-equal keys and its inverse (final position of the entry with id-rank r):
@@ -2140,9 +2154,15 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     BatchLds& L = sh.b;
     const int g = blockIdx.x;
     const int tid = threadIdx.x;
+    if (S.poison >= 0) {   // debug: LDS starts as this byte, not as what the previous workgroup on this CU left behind
+        uint32_t* const w = reinterpret_cast<uint32_t*>(&sh);
+        const uint32_t pat = 0x01010101u * (uint32_t)(S.poison & 0xFF);
+        for (size_t q = tid; q < sizeof(sh) / 4; q += NT) w[q] = pat;
+        BSYNC();
+    }
     if (tid == 0) {
         G = gd[g]; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0; s_anydep = 0; s_npatched = 0;
-        s_help[0] = 0; s_help[1] = 0;
+        s_help[0] = 0; s_help[1] = 0; s_help[2] = 0;
         // the input checks of the setup kernels are read here, not on the host (no mid-call synchronisation): bad input -> nothing is eliminated
         int32_t bad = 0;
         if (in_flags[FLAG_RANGE]) bad = ST_INDEX_RANGE;
@@ -2165,7 +2185,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             }
         }
     }
-    __syncthreads();
+    BSYNC();
     const int32_t n = G.n;
     const bool use_pq = A.o_v != OV_RANDOM;
     int64_t nelim = G.t < (int64_t)(n - 1) ? G.t : (int64_t)(n - 1);
@@ -2217,8 +2237,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             } else if (tid < 128) {
                 single_helper(sh.e, sh.g.c.newv, s_help);
             }
-            __syncthreads();
-            if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
+            BSYNC();
+            if (G.status != 0 || s_help[2] != 0) { if (tid == 0) s_status = G.status ? G.status : ST_INTERNAL; BSYNC(); break; }
             done += 1;
             PHASE_STAMP(5);
             continue;
@@ -2254,29 +2274,29 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     const int r = block_excl_scan<NWAVE>((vs ? 1 : 0) | (vo ? (1 << 16) : 0), L.scan, &tot);
                     const int rs = r & 0xFFFF, ro = r >> 16, ts = tot & 0xFFFF, to = tot >> 16;
                     const int base = s_nc;
-                    __syncthreads();
+                    BSYNC();
                     if (vs && base + rs < Bcur) { L.cand[base + rs].v = v_s; L.cand[base + rs].src = a; }
                     if (vo && base + ts + ro < Bcur) { L.cand[base + ts + ro].v = v_o; L.cand[base + ts + ro].src = ~oc; }
                     if (tid == 0) s_nc = (base + ts + to < Bcur) ? base + ts + to : Bcur;
-                    __syncthreads();
+                    BSYNC();
                     top = top > NT ? top - NT : 0;
                     if (last_stack) oc0 += NT;
                 }
                 if (s_nc > 0) break;
-                __syncthreads();
+                BSYNC();
                 if (tid == 0) {
                     A.bs_cnt[b] = 0; A.ocur[b] = oe;
                     G.minlist += 1;
                     if (G.minlist > 2 * n) s_status = ST_INTERNAL;
                 }
-                __syncthreads();
+                BSYNC();
                 if (s_status) break;
             }
             if (s_status) break;
         } else {
             if (tid < Bcur) { L.cand[tid].v = G.vbase + (int32_t)A.perm[G.vbase + n - (done + tid + 1)]; L.cand[tid].src = 0; }
             if (tid == 0) s_nc = Bcur;
-            __syncthreads();
+            BSYNC();
         }
         const int32_t nc = s_nc;
         PHASE_STAMP(0);
@@ -2290,7 +2310,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             batch_pos[v] = tid;
             if (L.cand[tid].flags & CF_BIG) atomicMin(&s_pmax, tid);   // a long column cuts the round: nothing is loaded behind it
         }
-        __syncthreads();
+        BSYNC();
         const bool first_is_big = (L.cand[0].flags & CF_BIG) != 0;   // goes to the single-vertex path: skip this round's prepare
         if (!first_is_big) {
             // BATCH*BCAP = 4*NT slots: issue every load before the first LDS store
@@ -2379,7 +2399,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 }
             }
             if (tid < nc && (L.cand[tid].flags & CF_BIG)) atomicMin(&s_pmax, tid);
-            __syncthreads();
+            BSYNC();
             const int32_t ncp = s_pmax < nc ? s_pmax : nc;   // candidates [ncp, nc) are behind the cut
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) if (SI(k) >= ncp) { la[k] = false; ready[k] = false; }
@@ -2658,7 +2678,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             }
             }   // BC <= 64
         }
-        __syncthreads();
+        BSYNC();
         PHASE_STAMP(1);
         // targets shared by several candidates are found with an LDS hash table (keys over pslot, counts over the
         // move arrays: both idle until the commit); cleared here, filled and read in P4 behind later barriers
@@ -2672,19 +2692,19 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
         // RNG offsets (P2): a prefix sum does not depend on what follows it, so it is taken over all candidates of the round
         int dtot;
         const int dex = block_excl_scan<NWAVE>((tid < nc && !first_is_big) ? L.cand[tid].ndraw : 0, L.scan, &dtot);
-        __syncthreads();
+        BSYNC();
         int32_t Pmax = first_is_big ? 0 : (s_pmax < nc ? s_pmax : nc);
         int32_t P = 0;
         PHASE_STAMP(2);
         if (Pmax > 0) {
             // (dtot covers the whole round: at most 4k uniforms more than the prefix needs; the table has that slack)
-            if (G.n_draws + dtot > A.rng_len) { if (tid == 0) s_status = ST_RNG_OVERFLOW; __syncthreads(); break; }
+            if (G.n_draws + dtot > A.rng_len) { if (tid == 0) s_status = ST_RNG_OVERFLOW; BSYNC(); break; }
             // ================= P3: sampling =================
             if (tid < Pmax) {
                 L.cand[tid].draw0 = G.n_draws + dex;
                 if (!PATCH || L.cand[tid].ndep == 0) cand_cumsum(A, L.cand[tid]);
             }
-            __syncthreads();
+            BSYNC();
             if (A.o_v != OV_COARSEN) {
                 #pragma unroll 1
                 for (int k = 0; k < PASSES; ++k) {   // slot-major pairs, rolled (code size): waves whose candidates are short skip later passes
@@ -2696,7 +2716,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 // empty unless the round is nearly full: it overlaps with the other waves' picks
                 if (tid >= NT - BATCH && tid - (NT - BATCH) < Pmax && (!PATCH || L.cand[tid - (NT - BATCH)].ndep == 0)) cand_recur(A, L.cand[tid - (NT - BATCH)]);
             }
-            __syncthreads();
+            BSYNC();
             PHASE_STAMP(3);
             if constexpr (PATCH) { if (s_anydep) {
                 // ---- dependent candidates: patched from the sampled records of the earlier candidates they are adjacent to, ordered
@@ -2719,7 +2739,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         int32_t f = *fp, spins = 0;
                         while (!(f & (CF_PATCHED | CF_DEP))) {
                             __builtin_amdgcn_s_sleep(1);
-                            if (++spins > (1 << 20)) { f = CF_DEP; break; }   // (never seen; a stuck wave must not hang the device)
+                            if (++spins > SPIN_LIMIT) { f = CF_DEP; if (lane == 0) s_status = ST_INTERNAL; break; }   // (a stuck wave must not hang the device -- and must not pass for a result)
                             f = *fp;
                         }
                         if (f & CF_DEP) lost = true;
@@ -2734,9 +2754,10 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         else { atomicOr(&C.flags, CF_DEP); atomicMin(&s_pmax, i); }
                     }
                 }
-                __syncthreads();
+                BSYNC();
                 Pmax = s_pmax < Pmax ? s_pmax : Pmax;
             } }
+            if constexpr (PATCH) { if (s_status) break; }   // (workgroup-uniform: read behind the barrier above or the one that ended P3)
             PHASE_STAMP(19);
             PHASE_STAMP(3);
             // ================= P4: PQ replay; targets shared by several candidates go in candidate order =================
@@ -2759,7 +2780,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     atomicAdd(&hcnt[hh], 1);
                 }
             }
-            __syncthreads();
+            BSYNC();
             PHASE_STAMP(33);
 #pragma unroll
             for (int k = 0; k < PASSES; ++k) {
@@ -2805,7 +2826,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     if (pq_list_of(k2, n) <= G.minlist) atomicMin(&s_p, i + 1);   // pre-empts the predicted order: last of the round
                 }
             }
-            __syncthreads();
+            BSYNC();
             PHASE_STAMP(34);
             // contended records: order by (x, i) with a rank sort (keys are distinct), then replay each group in order
             const int32_t ncont = s_ncont < CCAP ? s_ncont : CCAP;
@@ -2820,7 +2841,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 }
                 csorted[rank] = me;
             }
-            __syncthreads();
+            BSYNC();
             PHASE_STAMP(35);
             for (int32_t q = tid; q < ncont; q += NT) {
                 if (q > 0 && csorted[q - 1].x == csorted[q].x) continue;   // group head only
@@ -2842,7 +2863,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     key = k2;
                 }
             }
-            __syncthreads();
+            BSYNC();
             // ================= P: the first pre-empting / complex candidate was noted during the replay; bound the
             PHASE_STAMP(36);
             // number of moves (candidates sit in the first two waves: a wave scan and one word through LDS) =================
@@ -2851,11 +2872,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 int incl = mycnt;
                 for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
                 if (tid == 63) L.scan[0] = incl;
-                __syncthreads();
+                BSYNC();
                 static_assert(BATCH <= 128, "candidates live in waves 0 and 1");
                 if (tid < Pmax && incl + (tid >= 64 ? L.scan[0] : 0) > MCAP) atomicMin(&s_p, tid);
             }
-            __syncthreads();
+            BSYNC();
             P = s_p < Pmax ? s_p : Pmax;
             PHASE_STAMP(4);
         }
@@ -2863,13 +2884,13 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             // ================= single-vertex path for candidate 0 =================
             ++singles;
             const int32_t v0 = L.cand[0].v, src0 = L.cand[0].src;
-            __syncthreads();
+            BSYNC();
             if (tid < nc) batch_pos[L.cand[tid].v] = -1;
             if (tid == 0 && use_pq) {
                 if (src0 >= 0) A.bs_cnt[b] = src0; else { A.bs_cnt[b] = 0; A.ocur[b] = (~src0) + 1; }
                 A.vr[v0].pqpos = -2;
             }
-            __syncthreads();
+            BSYNC();
             if (tid < 64) {
                 // the out-of-line paths take the descriptors by reference: hand them private copies so that
                 // the kernel's own copy never has its address taken (it would otherwise live in scratch
@@ -2895,8 +2916,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 single_helper(sh.e, sh.g.c.newv, s_help);
             }
             if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_anydep = 0; s_npatched = 0; }
-            __syncthreads();
-            if (G.status != 0) { if (tid == 0) s_status = G.status; __syncthreads(); break; }
+            BSYNC();
+            if (G.status != 0 || s_help[2] != 0) { if (tid == 0) s_status = G.status ? G.status : ST_INTERNAL; BSYNC(); break; }
             done += 1;
             PHASE_STAMP(5);
             continue;
@@ -2988,7 +3009,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 }
                 L.scan[NWAVE + 1] = base;
             }
-            __syncthreads();
+            BSYNC();
             const int32_t pbase = L.scan[NWAVE + 1];
             if (pbase < 0) status = ST_POOL_OVERFLOW;
             PHASE_STAMP(10);
@@ -3095,7 +3116,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 }
             }
         }
-        if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_POOL_OVERFLOW; __syncthreads(); break; }
+        if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_POOL_OVERFLOW; BSYNC(); break; }
+        if (S.jitter > 0 && ((threadIdx.x >> 6) & 1)) for (int _q = 0; _q < S.jitter; ++_q) __builtin_amdgcn_s_sleep(8);
         PHASE_STAMP(6);
         // one thread per appended entry: twin rewritten in place + the new entry (:404-414)
 #pragma unroll
@@ -3113,7 +3135,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
         if (PATCH && s_npatched) {
             // entries of patched candidates whose twin is an entry an EARLIER candidate of this round appends (~twin = its place in the
             // slot table): that candidate's stores (first pass, above) come first, the rewrite in place (:404-406) or the kill (:429-430) second
-            __syncthreads();
+            BSYNC();
 #pragma unroll 1
             for (int k = 0; k < PASSES; ++k) {
                 const int32_t i = tid / (NT / BATCH), pp = k * (NT / BATCH) + tid % (NT / BATCH);
@@ -3129,7 +3151,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
         }
         PHASE_STAMP(11);
         const int32_t nmoves = s_nmoves;
-        if (nmoves > MCAP) { if (tid == 0) s_status = ST_INTERNAL; __syncthreads(); break; }
+        if (nmoves > MCAP) { if (tid == 0) s_status = ST_INTERNAL; BSYNC(); break; }
         if (use_pq && nmoves > 0) {
             static_assert(BC == 32 || OV == OV_RANDOM, "op numbers mv - m fit a 64-bit mask for 32-slot candidates");
             // ---- order of the moves = (bucket, candidate, op).  No sort: a move's place in (candidate, op) order is
@@ -3154,7 +3176,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 int incl = cnt_i;
                 for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
                 if (tid == 63) L.scan[NWAVE] = incl;
-                __syncthreads();
+                BSYNC();
                 for (int w = 0; w < NWAVE; ++w) bmin = min(bmin, (uint32_t)L.scan[w]);
                 if (tid < P) L.hidx[tid] = incl - cnt_i + (tid >= 64 ? L.scan[NWAVE] : 0);
                 // [NWAVE][RB] move counts per (wave, bucket above the lowest); pslot is idle now (SLOTS = NWAVE * 256 ints)
@@ -3164,14 +3186,14 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
 #pragma unroll
                 for (int k = 0; k < PASSES; ++k) wtab[k * NT + tid] = 0;
                 if (tid == 0) s_nhigh = 0;
-                __syncthreads();
+                BSYNC();
                 uint32_t* const lst32 = reinterpret_cast<uint32_t*>(L.mkey);
                 if (mine) {
                     const int32_t idx = L.hidx[ci] + __popcll(L.cmask[ci] & ((1ull << (cmv - L.cand[ci].m)) - 1ull));
                     lst32[idx] = (uint32_t)(kq0 >> 32);
                     L.mval[idx] = x0;
                 }
-                __syncthreads();
+                BSYNC();
                 if (mine) { list_my = (int32_t)lst32[tid]; x_my = L.mval[tid]; }
                 const uint32_t brel = (uint32_t)list_my - bmin;
                 const bool low = mine && brel < (uint32_t)RB, high = mine && brel >= (uint32_t)RB;
@@ -3198,7 +3220,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     }
                 }
                 if (high) { const int32_t q = atomicAdd(&s_nhigh, 1); if (q < HCAP) { hl_list[q] = list_my; hl_idx[q] = tid; } }
-                __syncthreads();
+                BSYNC();
                 const int32_t nhigh = s_nhigh;
                 fallback = nhigh > HCAP;
                 if (!fallback) {
@@ -3207,7 +3229,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         for (int w = 0; w < NWAVE; ++w) { const int t = wtab[w * RB + tid]; wtab[w * RB + tid] = acc; acc += t; }
                         btot[tid] = acc;
                     }
-                    __syncthreads();
+                    BSYNC();
                     if (tid < 64) {   // bucket starts: each lane of wave 0 takes RB/64 consecutive buckets
                         int tsum = 0;
 #pragma unroll
@@ -3219,7 +3241,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         for (int u = 0; u < RB / 64; ++u) { bstart[tid * (RB / 64) + u] = run; run += btot[tid * (RB / 64) + u]; }
                         if (tid == 63) s_nlow = inc2;
                     }
-                    __syncthreads();
+                    BSYNC();
                     if (low) {
                         rank_my = wtab[(tid >> 6) * RB + brel] + rank_w;
                         pos_my = bstart[brel] + rank_my;
@@ -3237,10 +3259,10 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     }
                 } else {
                     // the moves sit in (candidate, op) order: their place stands in for the (candidate, op) key
-                    __syncthreads();
+                    BSYNC();
                     L.mkey[tid] = mine ? (((uint64_t)(uint32_t)list_my << 32) | (uint32_t)tid) : ~0ull;
                     L.mval[tid] = x_my;
-                    __syncthreads();
+                    BSYNC();
                 }
             }
             if (fallback) {
@@ -3253,11 +3275,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     uint32_t bmin = tid < nmoves ? (uint32_t)(kq >> 32) : 0xFFFFFFFFu, bmax = tid < nmoves ? (uint32_t)(kq >> 32) : 0u;
                     for (int off = 32; off > 0; off >>= 1) { bmin = min(bmin, (uint32_t)__shfl_xor((int)bmin, off)); bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, off)); }
                     if (lane == 0) { L.scan[tid >> 6] = (int32_t)bmin; L.hidx[tid >> 6] = (int32_t)bmax; }
-                    __syncthreads();
+                    BSYNC();
                     for (int w = 0; w < NWAVE; ++w) { bmin = min(bmin, (uint32_t)L.scan[w]); bmax = max(bmax, (uint32_t)L.hidx[w]); }
                     int32_t npow = 64;
                     while (npow < nmoves) npow <<= 1;
-                    __syncthreads();
+                    BSYNC();
                     if (bmax - bmin < (1u << 16)) {
                         uint32_t k32 = tid < nmoves ? ((((uint32_t)(kq >> 32) - bmin) << 15) | ((uint32_t)kq & 0x7FFFu)) : 0xFFFFFFFFu;
                         uint32_t* lk = reinterpret_cast<uint32_t*>(L.mkey);
@@ -3267,9 +3289,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                                 uint32_t ko; int32_t vo;
                                 if (jj >= 64) {
                                     lk[tid] = k32; L.mval[tid] = vq;
-                                    __syncthreads();
+                                    BSYNC();
                                     ko = lk[tid ^ jj]; vo = L.mval[tid ^ jj];
-                                    __syncthreads();
+                                    BSYNC();
                                 } else {
                                     ko = (uint32_t)__shfl_xor((int)k32, jj);
                                     vo = __shfl_xor(vq, jj);
@@ -3278,7 +3300,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                                 if (swap) { k32 = ko; vq = vo; }
                             }
                         }
-                        __syncthreads();
+                        BSYNC();
                         kq = (k32 == 0xFFFFFFFFu) ? ~0ull : ((((uint64_t)((k32 >> 15) + bmin)) << 32) | (uint64_t)(k32 & 0x7FFFu));
                     } else {
                         for (int32_t k = 2; k <= npow; k <<= 1) {
@@ -3287,9 +3309,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                                 uint64_t ko; int32_t vo;
                                 if (jj >= 64) {
                                     L.mkey[tid] = kq; L.mval[tid] = vq;
-                                    __syncthreads();
+                                    BSYNC();
                                     ko = L.mkey[tid ^ jj]; vo = L.mval[tid ^ jj];
-                                    __syncthreads();
+                                    BSYNC();
                                 } else {
                                     uint32_t lo32 = (uint32_t)kq, hi32 = (uint32_t)(kq >> 32);
                                     uint32_t olo = (uint32_t)__shfl_xor((int)lo32, jj), ohi = (uint32_t)__shfl_xor((int)hi32, jj);
@@ -3302,7 +3324,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         }
                     }
                     L.mkey[tid] = kq; L.mval[tid] = vq;
-                    __syncthreads();
+                    BSYNC();
                 }
                 // ---- bucket-group head index of every move (inclusive max scan) ----
                 {
@@ -3318,7 +3340,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         int32_t incl = hv;
                         for (int off = 1; off < 64; off <<= 1) { int32_t tt = __shfl_up(incl, off); if (lane >= off) incl = max(incl, tt); }
                         if (lane == 63) L.scan[tid >> 6] = incl;
-                        __syncthreads();
+                        BSYNC();
                         int32_t pre = carry;
                         for (int w = 0; w < (tid >> 6); ++w) pre = max(pre, L.scan[w]);
                         incl = max(incl, pre);
@@ -3326,7 +3348,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         int32_t nc2 = carry;
                         for (int w = 0; w < NWAVE; ++w) nc2 = max(nc2, L.scan[w]);
                         carry = nc2;
-                        __syncthreads();
+                        BSYNC();
                     }
                 }
                 if (mine) {
@@ -3355,8 +3377,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     else A.bs_dir[(int64_t)bk * BDIR + c_my] = base;
                 }
             }
-            if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_LOG_OVERFLOW; __syncthreads(); break; }
+            // the push ids of this round start at G.push_cnt: read BEFORE the barrier -- thread 0 advances the counter behind it, and a wave
+            // that came out of the barrier late used to read the advanced value (ids of two rounds overlapped: a wrong LIFO order inside a
+            // bucket, once in some thousand batched calls -- the "graph 851" mismatch of round 2)
             const int32_t id0 = G.push_cnt;
+            if (__syncthreads_or(status != 0)) { if (tid == 0) s_status = ST_LOG_OVERFLOW; BSYNC(); break; }
+            if (S.jitter > 0 && ((threadIdx.x >> 6) & 1)) for (int _q = 0; _q < S.jitter; ++_q) __builtin_amdgcn_s_sleep(8);
             if (mine) {
                 int32_t sl = A.bs_dir[(int64_t)bk * BDIR + c_my] + (a_my - bs_chunk_start(c_my));
                 A.bs_v[sl] = x_my; A.bs_id[sl] = id0 + pos_my;
@@ -3380,9 +3406,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
         }
         done += P;
         pending_long = (OV == OV_RANDOM) && P < nc && (L.cand[P].flags & CF_BIG) != 0;
-        __syncthreads();
+        BSYNC();
     }
-    __syncthreads();
+    BSYNC();
     if (tid == 0) {
         G.n_elim = (int32_t)nelim;
         if (s_status) G.status = s_status;
@@ -3391,6 +3417,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
         gd[g] = G;
     }
 }
+#undef BSYNC
 
 // The handle's tables of std::sort's permutation of 17..BC all-equal keys (layout: rlap_kernels.h EQTAB_*), built once.
 template <int BC>
@@ -3487,12 +3514,16 @@ __global__ void k_sc_perm_order(const int64_t* __restrict__ perm, const int32_t*
     if (q >= D.n_elim) order[surv_base[g] + (q - D.n_elim)] = (uint32_t)(D.vbase + (int32_t)pl);
 }
 
+// Rejected input (range / cross-graph / node_id flags, asymmetry: the same tests the elimination kernel makes) gives every column
+// the extent 0: the output pass then stages and writes nothing -- an invalid node_id vector can name one hub S times, which would
+// run past the staging arrays (sized one row per slot in use).
 __global__ void k_sc_ext(const uint32_t* __restrict__ order, const int32_t* __restrict__ colptr, const VRec* __restrict__ vr,
-                         int32_t S, int32_t* __restrict__ ext) {
+                         int32_t S, const int32_t* __restrict__ in_flags, const double* __restrict__ in_acc, int32_t* __restrict__ ext) {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S) return;
+    const bool bad = in_flags[FLAG_RANGE] || in_flags[FLAG_CROSS] || in_flags[FLAG_PERM] || in_acc[2] != 0.0 || !(in_acc[0] <= 1e-24 * in_acc[1]);
     int32_t v = (int32_t)order[i];
-    ext[i] = (colptr[v + 1] - colptr[v]) + vr[v].app_cnt;
+    ext[i] = bad ? 0 : (colptr[v + 1] - colptr[v]) + vr[v].app_cnt;
 }
 
 struct RecKeyLessDbg { const SRec* r; __device__ bool operator()(uint16_t a, uint16_t b) const { return r[a].key < r[b].key; } };
@@ -3931,7 +3962,7 @@ __global__ __launch_bounds__(64) void k_sc_merge_half(Arrays A, const GraphDesc*
 
 void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, const int32_t* vgraph, const uint32_t* order, const int32_t* ext,
                      const int64_t* tmp_off, int32_t S, int32_t* tmp_nbr, double* tmp_val, int32_t* cnt_out, const ScScratch& SS,
-                     unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* biglists, uint16_t* hugelists) {
+                     unsigned long long* live_total, int32_t* lists, int32_t* counts, uint16_t* hugelists) {
     const int keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) ? 1 : 0;
     hipStream_t stream = X.main;
     hipLaunchKernelGGL(k_sc_tierlists, dim3((S + 1023) / 1024), dim3(1024), 0, stream, ext, S, keyed, lists, counts);
@@ -3952,7 +3983,7 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
     hipLaunchKernelGGL((k_sc_merge_mw<4>), dim3(1024), dim3(256), MW_MID_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 6 * (size_t)S, counts + 6,
                        tmp_nbr, tmp_val, cnt_out, live_total, (int32_t)MIDCAP, (int32_t)MW_MID_QCAP);
     hipLaunchKernelGGL(k_sc_merge_big, dim3(2048), dim3(64), MID1_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 7 * (size_t)S, counts + 7,
-                       tmp_nbr, tmp_val, cnt_out, live_total, biglists, (int32_t)MID1CAP);
+                       tmp_nbr, tmp_val, cnt_out, live_total, nullptr, (int32_t)MID1CAP);   // (stop lists in LDS: no global list region)
     hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s1, A, gd, vgraph, order, ext, tmp_off, lists + 4 * (size_t)S, counts + 4,
                        tmp_nbr, tmp_val, cnt_out, live_total, hugelists, SS.rec, SS.top, SS.cap, SS.flags);
     unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);

@@ -32,13 +32,35 @@ last_stats = None  # rlap_stats of the most recent call (dict), for benches/test
 
 
 class _Handle:
+    """C-ABI handle plus the two torch tensors it works in: the per-call arena and the cached uniform table.  The library
+    allocates nothing itself (rlap_set_workspace): like the reference's result tensor (py_api_binder.cc:42) the memory comes
+    from torch's caching allocator, so the op runs inside a training loop that holds most of the device memory."""
+
     def __init__(self, lib, idx):
         self.lib = lib
         self.ptr = ctypes.c_void_p()
+        self.ws = None
+        self.rng = None
         with torch.cuda.device(idx):
             rc = lib.rlap_create(ctypes.byref(self.ptr))
         if rc != 0:
             raise RuntimeError(f"rlap_create failed: {_lib.status_string(rc)}")
+
+    def fit(self, dev, ws_bytes: int, rng_entries: int):
+        """Make the arena / table at least this large (grow-only, 12.5 % slack: no reallocation inside a size class)."""
+        changed = False
+        if self.ws is None or self.ws.numel() < ws_bytes:
+            self.ws = None   # (released first: the allocator may hand the same block back, grown)
+            self.ws = torch.empty(int(ws_bytes) + int(ws_bytes) // 8 + 4096, dtype=torch.uint8, device=dev)
+            changed = True
+        if self.rng is None or self.rng.numel() < rng_entries:
+            self.rng = None
+            self.rng = torch.empty(int(rng_entries) + int(rng_entries) // 8 + 1024, dtype=torch.float64, device=dev)
+            changed = True
+        if changed:
+            rc = self.lib.rlap_set_workspace(self.ptr, self.ws.data_ptr(), self.ws.numel(), self.rng.data_ptr(), self.rng.numel())
+            if rc != 0:
+                _raise(rc)
 
     def __del__(self):
         try:
@@ -56,7 +78,7 @@ def _device_for(t: Optional[Tensor]) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def _handle(device: torch.device):
+def _handle_obj(device: torch.device):
     lib = _lib.load()
     idx = device.index if device.index is not None else torch.cuda.current_device()
     handles = getattr(_tls, "handles", None)
@@ -68,11 +90,39 @@ def _handle(device: torch.device):
     h = hobj.ptr
     lib.rlap_set_stream(h, ctypes.c_void_p(torch.cuda.current_stream(idx).cuda_stream))
     lib.rlap_set_timing(h, 1 if _timing else 0)
-    return lib, h
+    return lib, hobj
 
 
-def set_timing(enable: bool, device=None):
-    """Fill the ms_* fields of `last_stats` with HIP-event timings (all handles of this process)."""
+def _handle(device: torch.device):
+    lib, hobj = _handle_obj(device)
+    return lib, hobj.ptr
+
+
+def _run(hobj, dev, E: int, n_total: int, G: int, symmetrize: bool, call, st):
+    """One op call inside torch-owned memory: size the arena for (E, n_total, G), call, and when the library reports
+    that it wants more (a growth limit was met and the repeated attempt is of a larger size class) grow and call again."""
+    lib = hobj.lib
+    ws_b, rng_n = ctypes.c_size_t(0), ctypes.c_int64(0)
+    rc = lib.rlap_workspace_query(hobj.ptr, E, n_total, G, 1 if symmetrize else 0, ctypes.byref(ws_b), ctypes.byref(rng_n))
+    if rc != 0:
+        _raise(rc)
+    hobj.fit(dev, ws_b.value, rng_n.value)
+    retries = 0
+    for _ in range(8):
+        rc = call()
+        retries += int(st.n_retries)
+        if rc != _lib.E_WORKSPACE:
+            break
+        rc2 = lib.rlap_workspace_needed(hobj.ptr, ctypes.byref(ws_b), ctypes.byref(rng_n))
+        if rc2 != 0:
+            _raise(rc2)
+        hobj.fit(dev, ws_b.value, rng_n.value)
+    st.n_retries = retries
+    return rc
+
+
+def set_timing(enable: bool):
+    """Fill the ms_* fields of `last_stats` with HIP-event timings (process-wide: every handle, every device)."""
     global _timing
     _timing = bool(enable)
 
@@ -83,6 +133,26 @@ def debug_set_limits(pool_factor: float = -1.0, log_factor: float = -1.0, rng_le
     dev = _device_for(None) if device is None else torch.device(device)
     lib, h = _handle(dev)
     rc = lib.rlap_debug_set_limits(h, float(pool_factor), float(log_factor), int(rng_len), int(scratch_entries))
+    if rc != 0:
+        _raise(rc)
+
+
+def debug_set_poison(byte: int = -1, device=None):
+    """Debug aid: fill the workspace, the output buffer and the elimination kernel's LDS with `byte` before every attempt of
+    the calling thread's next calls (negative = off); see include/rlap_hip.h."""
+    dev = _device_for(None) if device is None else torch.device(device)
+    lib, h = _handle(dev)
+    rc = lib.rlap_debug_set_poison(h, int(byte))
+    if rc != 0:
+        _raise(rc)
+
+
+def debug_set_jitter(quarter_us: int = 0, device=None):
+    """Debug aid: waves of the elimination kernel sleep `quarter_us` x 0.25 us behind its barriers, a different subset each time
+    (0 = off); see include/rlap_hip.h.  Results must not depend on it."""
+    dev = _device_for(None) if device is None else torch.device(device)
+    lib, h = _handle(dev)
+    rc = lib.rlap_debug_set_jitter(h, int(quarter_us))
     if rc != 0:
         _raise(rc)
 
@@ -137,30 +207,26 @@ def approximate_cholesky(
     assert o_n in ["asc", "desc", "random"]
     global last_stats
     dev = _device_for(edge_index)
-    lib, h = _handle(dev)
+    lib, hobj = _handle_obj(dev)
+    h = hobj.ptr
     with torch.cuda.device(dev):
         row, col, w, E = _prep_edges(edge_index, edge_weights, dev)
         n = int(num_nodes)
         d_perm = None
-        if o_v == "random":
-            if perm is None:
-                # the reference shuffles 0..n-1 with std::random_device (preconditioner.cc:594-596); here torch's
-                # device generator (or `seed`) draws it, on the device
-                gen = None
-                if seed is not None:
-                    gen = torch.Generator(device=dev)
-                    gen.manual_seed(int(seed) & (2**63 - 1))
-                perm = torch.randperm(n, generator=gen, device=dev)
+        if o_v == "random" and perm is not None:
             d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
             assert d_perm.numel() == n
-        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v == "coarsen") else 0
+        # perm None: the reference shuffles 0..n-1 with std::random_device (preconditioner.cc:594-596); here the node_id vector is
+        # drawn on the device from `seed` by the C ABI's keyed shuffle -- the same draw as approximate_cholesky_from_edges and as
+        # graph 0 of approximate_cholesky_batched with that seed (ONE meaning of `seed` in this module)
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree") else 0
         out = torch.empty((max(E, 1), 3), dtype=torch.float64, device=dev)
         rows = ctypes.c_int64(0)
         st = _lib.Stats()
-        rc = lib.rlap_approx_chol(
+        rc = _run(hobj, dev, E, n, 1, False, lambda: lib.rlap_approx_chol(
             h, row.data_ptr(), col.data_ptr(), w.data_ptr() if w is not None else None, E, n, int(num_remove),
             O_V[o_v], O_N[o_n], d_perm.data_ptr() if d_perm is not None else None, shuffle_seed,
-            out.data_ptr(), out.shape[0], ctypes.byref(rows), ctypes.byref(st))
+            out.data_ptr(), out.shape[0], ctypes.byref(rows), ctypes.byref(st)), st)
         if rc != 0:
             _raise(rc)
         last_stats = st.as_dict()
@@ -194,7 +260,8 @@ def approximate_cholesky_from_edges(
     assert o_n in ["asc", "desc", "random"]
     global last_stats
     dev = _device_for(edge_index)
-    lib, h = _handle(dev)
+    lib, hobj = _handle_obj(dev)
+    h = hobj.ptr
     with torch.cuda.device(dev):
         row, col, w, E = _prep_edges(edge_index, edge_weights, dev)
         n = -1 if num_nodes is None else int(num_nodes)
@@ -211,10 +278,12 @@ def approximate_cholesky_from_edges(
         rows = ctypes.c_int64(0)
         nn = ctypes.c_int64(0)
         st = _lib.Stats()
-        rc = lib.rlap_approx_chol_from_edges(
+        # num_nodes unknown (found on the device inside the call): a graph has no more vertices than endpoints -- an upper bound for the arena
+        n_ub = n if n >= 0 else max(2 * E, 1)
+        rc = _run(hobj, dev, E, n_ub, 1, bool(symmetrize), lambda: lib.rlap_approx_chol_from_edges(
             h, row.data_ptr(), col.data_ptr(), w.data_ptr() if w is not None else None, E, n, t, float(remove_frac),
             1 if symmetrize else 0, O_V[o_v], O_N[o_n], d_perm.data_ptr() if d_perm is not None else None, shuffle_seed,
-            out.data_ptr(), out.shape[0], ctypes.byref(rows), ctypes.byref(nn), ctypes.byref(st))
+            out.data_ptr(), out.shape[0], ctypes.byref(rows), ctypes.byref(nn), ctypes.byref(st)), st)
         if rc != 0:
             _raise(rc)
         last_stats = st.as_dict()
@@ -250,7 +319,8 @@ def approximate_cholesky_batched(
     assert o_n in ["asc", "desc", "random"]
     global last_stats
     dev = _device_for(edge_index)
-    lib, h = _handle(dev)
+    lib, hobj = _handle_obj(dev)
+    h = hobj.ptr
     np_ = torch.as_tensor(node_ptr, dtype=torch.int64).cpu().contiguous()
     nr_ = torch.as_tensor(num_remove, dtype=torch.int64).cpu().contiguous()
     G = np_.numel() - 1
@@ -268,11 +338,11 @@ def approximate_cholesky_batched(
         out = torch.empty((max(E, 1), 3), dtype=torch.float64, device=dev)
         row_ptr = torch.zeros(G + 1, dtype=torch.int64)
         st = _lib.Stats()
-        rc = lib.rlap_approx_chol_batched(
+        rc = _run(hobj, dev, E, N, G, False, lambda: lib.rlap_approx_chol_batched(
             h, row.data_ptr(), col.data_ptr(), w.data_ptr() if w is not None else None, E, G,
             np_.data_ptr(), nr_.data_ptr(), O_V[o_v], O_N[o_n],
             d_perm.data_ptr() if d_perm is not None else None, shuffle_seed,
-            out.data_ptr(), out.shape[0], row_ptr.data_ptr(), ctypes.byref(st))
+            out.data_ptr(), out.shape[0], row_ptr.data_ptr(), ctypes.byref(st)), st)
         if rc != 0:
             _raise(rc)
         last_stats = st.as_dict()
@@ -303,10 +373,11 @@ def identity(a: Tensor) -> Tensor:
 def rng_uniforms(count: int, device=None) -> Tensor:
     """First `count` uniforms of the sampling stream as generated on the device."""
     dev = _device_for(None) if device is None else torch.device(device)
-    lib, h = _handle(dev)
+    lib, hobj = _handle_obj(dev)
     with torch.cuda.device(dev):
         out = torch.empty(count, dtype=torch.float64, device=dev)
-        rc = lib.rlap_rng_uniforms(h, count, out.data_ptr())
+        hobj.fit(dev, 0, max(int(count), 1 << 16))
+        rc = lib.rlap_rng_uniforms(hobj.ptr, count, out.data_ptr())
         if rc != 0:
             _raise(rc)
     return out
