@@ -69,8 +69,8 @@ def compute_ppr(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], n
     This restates PyGCL's `GCL.augmentors.functional.compute_ppr` (called by
     scripts/augmentor_benchmarks.py:152-159 with ignore_edge_attr=False, add_self_loop=False), which chains
     PyG's GDC steps: transition_matrix('sym') -> diffusion_matrix_exact('ppr') -> sparsify_dense('threshold')
-    -> transition_matrix('sym').  PyGCL and PyG are third-party packages absent from this container
-    (PyGCL is unpinned in the reference's requirements.txt), so this row is UNPINNED: it follows the published
+    -> transition_matrix('sym').  PyGCL (pinned by the reference: requirements.txt:4, PyGCL==0.1.2) and PyG are third-party
+    packages absent from this container and not installable (no network), so this row is UNPINNED: it follows the published
     semantics of those functions, not a run of them.  `normalize_out=False` gives
     the diffusion matrix before the last step.  torch ops on the input's device; meant for the sizes the
     reference uses it on (the Schur-complement subgraph)."""
@@ -99,11 +99,16 @@ class rLapPPRDiffusion:
     `refresh_cache_freq` calls like the reference."""
 
     def __init__(self, frac, o_v="random", o_n="asc", alpha=0.2, eps=1e-4, use_cache=True, refresh_cache_freq=50, seed=None,
-                 num_nodes_from_x=False, normalize_out=True):
+                 num_nodes_from_x=False, normalize_out=True, weights_dtype=torch.float64):
         self.frac, self.o_v, self.o_n, self.alpha, self.eps = frac, o_v, o_n, alpha, eps
         self.use_cache, self.refresh_cache_freq = use_cache, refresh_cache_freq
         self._cache, self.refresh_cache_counter, self.seed = None, 0, seed
         self.num_nodes_from_x, self.normalize_out = num_nodes_from_x, normalize_out
+        # The reference hands compute_ppr `torch.Tensor(sparse_edge_info[:, -1])` (augmentor_benchmarks.py:144-146).  On the torch of
+        # this image (2.10) that expression keeps float64 (checked: torch.Tensor(f64 tensor).dtype is float64); on the legacy
+        # constructor of older torch builds it is the default tensor type, float32.  float64 is the default here;
+        # weights_dtype=torch.float32 rounds the Schur-complement weights once before the diffusion, as such a build would.
+        self.weights_dtype = weights_dtype
 
     def augment(self, g):
         if self._cache is not None and self.use_cache and self.refresh_cache_counter < self.refresh_cache_freq:
@@ -117,7 +122,7 @@ class rLapPPRDiffusion:
         relabel = torch.full((num_nodes,), -1, dtype=torch.int64, device=ei.device)
         relabel[nodes] = torch.arange(nodes.numel(), device=ei.device)
         sub_ei = relabel[ei]
-        d_ei, d_w = compute_ppr(sub_ei, sc[:, 2], nodes.numel(), alpha=self.alpha, eps=self.eps, normalize_out=self.normalize_out)
+        d_ei, d_w = compute_ppr(sub_ei, sc[:, 2].to(self.weights_dtype), nodes.numel(), alpha=self.alpha, eps=self.eps, normalize_out=self.normalize_out)
         res = Graph(x, nodes[d_ei], d_w)
         self._cache, self.refresh_cache_counter = res, 0
         return res
