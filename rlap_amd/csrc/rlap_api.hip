@@ -217,14 +217,18 @@ struct WBuf { void* p = nullptr; template <class T> T* as() const { return reint
 struct WS {
     WBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, colptr, slot_col, permchk, genperm, ent, vrec, ocur, oend, origpos, orig_order, gd_d, pool_top, bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, skey0, skey1, sval0, sval1, scr_rec, scr_i32, scr_f64, surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, sc_rec, sc_i32, sc_f64, biglist, hugelists, results;
 };
+inline size_t host_block_bytes(int64_t G) { return 16 * (size_t)(G + 1) + sizeof(GraphDesc) * (size_t)G; }
 // the arena's layout: run once with a null base to learn the size, once more to place the buffers
 size_t carve(Carver& C, const Sizes& z, WS& W) {
     const int64_t G = z.G, N = z.N, S = z.S, Ealloc = std::max<int64_t>(z.Eeff, 1), BT = z.bucket_total;
     W.scal.p = C.take<Scalars>(1);
     W.results.p = C.take<char>((int64_t)z.res_bytes);
-    W.node_ptr_d.p = C.take<int64_t>(G + 1);
-    W.gd_d.p = C.take<GraphDesc>(G);
-    W.surv_base_d.p = C.take<int64_t>(G + 1);
+    {   // what the host hands over per call, one block (one H2D copy from the pinned staging buffer): node_ptr | surv_base | gd
+        char* hp = C.take<char>((int64_t)host_block_bytes(G));
+        W.node_ptr_d.p = hp;
+        W.surv_base_d.p = hp ? hp + 8 * (G + 1) : nullptr;
+        W.gd_d.p = hp ? hp + 16 * (G + 1) : nullptr;
+    }
     W.pool_top.p = C.take<int32_t>(1);
     W.bs_pool_top.p = C.take<int32_t>(1);
     W.vgraph.p = C.take<int32_t>(N);
@@ -353,11 +357,14 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
             if (c.d_out && c.out_cap > 0) HIPCHK(hipMemsetAsync(c.d_out, h->poison, sizeof(double) * 3 * (size_t)c.out_cap, s));
         }
     }
-    if (res_bytes > h->h_results_cap) {
-        if (h->h_results) (void)hipHostFree(h->h_results);
-        h->h_results = nullptr; h->h_results_cap = 0;
-        HIPCHK(hipHostMalloc(&h->h_results, res_bytes + 65536, hipHostMallocDefault));
-        h->h_results_cap = res_bytes + 65536;
+    {
+        const size_t pinned_need = ((res_bytes + 255) & ~(size_t)255) + host_block_bytes(G);   // read-back block + staging of the host parameters
+        if (pinned_need > h->h_results_cap) {
+            if (h->h_results) (void)hipHostFree(h->h_results);
+            h->h_results = nullptr; h->h_results_cap = 0;
+            HIPCHK(hipHostMalloc(&h->h_results, pinned_need + 65536, hipHostMallocDefault));
+            h->h_results_cap = pinned_need + 65536;
+        }
     }
     { int rc = ensure_rng(h, rng_guess(h, Eeff, G)); if (rc) return rc; }
     const SortTmp ST{W.sorttmp.p, z.sort_tmp};
@@ -372,9 +379,15 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     int32_t* nnz_p = &SC->nnz;
 
     // ---------------- setup: COO -> CSR ----------------
-    HIPCHK(hipMemcpyAsync(W.node_ptr_d.p, c.h_node_ptr, sizeof(int64_t) * (G + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(W.gd_d.p, gd.data(), sizeof(GraphDesc) * G, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(W.surv_base_d.p, surv_base.data(), 8 * (G + 1), hipMemcpyHostToDevice, s));
+    {
+        // node_ptr | surv_base | gd: staged in pinned host memory (behind the read-back block), ONE asynchronous copy -- three copies
+        // from pageable memory were three blocking staging copies inside the runtime
+        char* stage = static_cast<char*>(h->h_results) + ((res_bytes + 255) & ~(size_t)255);
+        std::memcpy(stage, c.h_node_ptr, 8 * (size_t)(G + 1));
+        std::memcpy(stage + 8 * (G + 1), surv_base.data(), 8 * (size_t)(G + 1));
+        std::memcpy(stage + 16 * (G + 1), gd.data(), sizeof(GraphDesc) * (size_t)G);
+        HIPCHK(hipMemcpyAsync(W.node_ptr_d.p, stage, host_block_bytes(G), hipMemcpyHostToDevice, s));
+    }
     {
         Fills F;
         F.add(W.scal.p, sizeof(Scalars) / 4, 0);
@@ -427,12 +440,13 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         hipLaunchKernelGGL(k_heads, dim3(nblk(Eeff + 1, 256)), dim3(256), 0, s, keys_sorted, Eeff, W.head.as<int32_t>());
         int rc = excl_scan(h, ST, W.head.as<int32_t>(), W.pos.as<int32_t>(), Eeff + 1);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(nnz_p, W.pos.as<int32_t>() + Eeff, 4, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_fill_csr, dim3(nblk(Eeff, 256)), dim3(256), 0, s, keys_sorted, idx_sorted, W.head.as<int32_t>(),
                            W.pos.as<int32_t>(), c.d_w, Eeff, (c.symmetrize && !c.d_w) ? 1 : 0, kbits, W.ent.as<Slot>(), W.slot_col.as<int32_t>(),
                            reinterpret_cast<int32_t*>(rowid));
     }
-    hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, W.slot_col.as<int32_t>(), nnz_p, (int32_t)N, W.colptr.as<int32_t>());
+    // (nnz = pos[Eeff]: k_colptr reads it there and files it in the scalar block and as the pool's first free slot)
+    hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, W.slot_col.as<int32_t>(), Eeff > 0 ? W.pos.as<int32_t>() + Eeff : (const int32_t*)nnz_p, (int32_t)N,
+                       W.colptr.as<int32_t>(), nnz_p, W.pool_top.as<int32_t>());
     if (Eeff > 0) {
         // twins: stable sort of the slots by row id (keys0 is free again: sorted keys in its first half, the slot order T in its second)
         uint32_t* skeys = W.keys0.as<uint32_t>();
@@ -446,7 +460,6 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         hipLaunchKernelGGL(k_twin_sorted, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, W.ent.as<Slot>(), T, nnz_p, acc);
         hipLaunchKernelGGL(k_twin_store, dim3((unsigned)std::min<int64_t>(nblk(Eeff, 256), 4096)), dim3(256), 0, s, W.ent.as<Slot>(), T, nnz_p);
     }
-    HIPCHK(hipMemcpyAsync(W.pool_top.p, nnz_p, 4, hipMemcpyDeviceToDevice, s));
     // per-graph scratch of the long-column fall-backs (needs the per-graph nnz: filled on the device)
     hipLaunchKernelGGL(k_gd_scratch, dim3(1), dim3(256), 0, s, W.colptr.as<int32_t>(), W.node_ptr_d.as<int64_t>(), (int32_t)G, W.gd_d.as<GraphDesc>());
 
@@ -456,10 +469,9 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
                        W.skey0.as<uint64_t>(), W.sval0.as<uint32_t>());
     {
         // key = graph << 32 | degree: only the bits that can be set take part in the sort
-        int rc = sort_pairs(h, ST, W.skey0.as<uint64_t>(), W.skey1.as<uint64_t>(), W.sval0.as<uint32_t>(), W.sval1.as<uint32_t>(), N, 0, 32 + gbits);
+        int rc = sort_pairs(h, ST, W.skey0.as<uint64_t>(), W.skey1.as<uint64_t>(), W.sval0.as<uint32_t>(), W.orig_order.as<uint32_t>(), N, 0, 32 + gbits);
         if (rc) return rc;
     }
-    HIPCHK(hipMemcpyAsync(W.orig_order.p, W.sval1.p, 4 * N, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, W.orig_order.as<uint32_t>(), W.vrec.as<VRec>(), W.vgraph.as<int32_t>(),
                        W.gd_d.as<GraphDesc>(), (int32_t)N, W.ocur.as<int32_t>(), W.oend.as<int32_t>(), W.origpos.as<int32_t>());
 

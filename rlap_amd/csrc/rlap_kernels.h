@@ -103,7 +103,7 @@ __global__ void k_fill_csr(const uint64_t* keys, const uint32_t* idx, const int3
                            int64_t E, int set_semantics, int kbits, Slot* ent, int32_t* slot_col, int32_t* nbr32);
 __global__ void k_twin_sorted(const Slot* ent, const uint32_t* T, const int32_t* nnz_p, double* acc);
 __global__ void k_twin_store(Slot* ent, const uint32_t* T, const int32_t* nnz_p);
-__global__ void k_colptr(const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int32_t* colptr);
+__global__ void k_colptr(const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int32_t* colptr, int32_t* nnz_out, int32_t* pool_top_out);
 __global__ void k_pq_init(const int32_t* colptr, const int32_t* vgraph, int32_t N, VRec* vr, uint64_t* skey, uint32_t* sval);
 __global__ void k_bucket_bounds(const uint32_t* order, const VRec* vr, const int32_t* vgraph, const GraphDesc* gd, int32_t N,
                                 int32_t* ocur, int32_t* oend, int32_t* origpos);

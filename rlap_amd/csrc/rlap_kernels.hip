@@ -287,9 +287,13 @@ __global__ void k_fill_csr(const uint64_t* __restrict__ keys, const uint32_t* __
 }
 
 // colptr[c] = first slot whose column is >= c (slots are sorted by column): no atomics, empty columns included
-__global__ void k_colptr(const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nnz_p, int32_t N, int32_t* __restrict__ colptr) {
+// (thread 0 also files the entry count where the later kernels read it and starts the append pool behind the CSR image:
+//  two 4-byte device-to-device copies less per call)
+__global__ void k_colptr(const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nnz_p, int32_t N, int32_t* __restrict__ colptr,
+                         int32_t* __restrict__ nnz_out, int32_t* __restrict__ pool_top_out) {
     int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > N) return;
+    if (c == 0) { const int32_t z = *nnz_p; *nnz_out = z; *pool_top_out = z; }
     int32_t lo = 0, hi = *nnz_p;
     while (lo < hi) {
         int32_t mid = (lo + hi) >> 1;
@@ -2142,6 +2146,12 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     __shared__ GraphDesc G;
     __shared__ int32_t s_help[3];      // hand-over between the eliminating wave and its helper (single_helper); [2]: the helper gave up waiting
     __shared__ int32_t s_nc, s_pmax, s_p, s_ncont, s_nmoves, s_status, s_nhigh, s_nlow, s_pool_cur, s_pool_end, s_anydep, s_npatched;
+    // chunk directory of the bucket the pops come from, kept in LDS between rounds: the prediction's stack window then starts with
+    // the entries themselves instead of a dependent look-up of their chunk base (one global round trip less per round).
+    // s_dirb = that bucket (global index), -1 none; refreshed when the bucket changes, a push allocates a chunk for it (push phase,
+    // same thread) or the single-vertex path has pushed (it allocates through bs_ensure)
+    __shared__ int32_t s_dirb;
+    __shared__ int32_t s_dir[BDIR];
     constexpr int32_t POOL_GRAB = NT >= 1024 ? POOL_GRAB_BIG : POOL_GRAB_SMALL;   // slots reserved at a time for the round's appends
     // std::sort's permutation of n = 17..BC all-equal keys and its inverse (final position of the entry with id-rank r):
     // in LDS for the 1024-thread shape; the 256-thread shape reads the handle's tables (k_eq_tables) through the L1,
@@ -2162,7 +2172,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     }
     if (tid == 0) {
         G = gd[g]; s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_pool_cur = 0; s_pool_end = 0; s_anydep = 0; s_npatched = 0;
-        s_help[0] = 0; s_help[1] = 0; s_help[2] = 0;
+        s_help[0] = 0; s_help[1] = 0; s_help[2] = 0; s_dirb = -1;
         // the input checks of the setup kernels are read here, not on the host (no mid-call synchronisation): bad input -> nothing is eliminated
         int32_t bad = 0;
         if (in_flags[FLAG_RANGE]) bad = ST_INDEX_RANGE;
@@ -2254,6 +2264,11 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 const int32_t cnt = A.bs_cnt[b];
                 int32_t oc0 = A.ocur[b];
                 const int32_t oe = A.oend[b];
+                if (s_dirb != b) {   // (workgroup-uniform: s_dirb changes only in front of a barrier)
+                    if (tid < BDIR) s_dir[tid] = A.bs_dir[(int64_t)b * BDIR + tid];
+                    BSYNC();
+                    if (tid == 0) s_dirb = b;
+                }
                 // moved members, newest first, then the never-moved members in descending id.  The window of
                 // the stack that reaches its bottom is read together with the first window of the never-moved
                 // members (both load chains in flight at once, one block scan for the two).
@@ -2263,7 +2278,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     bool vs = false, vo = false;
                     int32_t v_s = -1, v_o = -1;
                     if (a >= 0) {
-                        int32_t sl = bs_slot(A, b, a);
+                        const int cdir = bs_chunk_of(a);
+                        const int32_t sl = s_dir[cdir] + (a - bs_chunk_start(cdir));
                         v_s = A.bs_v[sl];
                         vs = (A.vr[v_s].pqpos == A.bs_id[sl]);
                     }
@@ -2915,7 +2931,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
             } else if (tid < 128) {
                 single_helper(sh.e, sh.g.c.newv, s_help);
             }
-            if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_anydep = 0; s_npatched = 0; }
+            if (tid == 0) { s_nc = 0; s_pmax = BATCH + 1; s_p = BATCH + 1; s_ncont = 0; s_nmoves = 0; s_anydep = 0; s_npatched = 0; s_dirb = -1; }
             BSYNC();
             if (G.status != 0 || s_help[2] != 0) { if (tid == 0) s_status = G.status ? G.status : ST_INTERNAL; BSYNC(); break; }
             done += 1;
@@ -3374,7 +3390,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     int32_t need = bs_chunk_cap(c_my);
                     int32_t base = atomicAdd(A.bs_pool_top, need);
                     if (base < 0 || base > A.bs_pool_cap - need) status = ST_LOG_OVERFLOW;
-                    else A.bs_dir[(int64_t)bk * BDIR + c_my] = base;
+                    else { A.bs_dir[(int64_t)bk * BDIR + c_my] = base; if (bk == s_dirb) s_dir[c_my] = base; }
                 }
             }
             // the push ids of this round start at G.push_cnt: read BEFORE the barrier -- thread 0 advances the counter behind it, and a wave
