@@ -6,7 +6,7 @@
 # 3. --pmc SQ_* on the same command                        -> issue / wait picture of the elimination kernel
 # 4. --kernel-trace --stats of bench.py --workload c5      -> kernel durations of the batched workload
 # Raw outputs land in gpurun_out/prof_<round>/ ; tools/profile_summarize.py condenses them into profiles/.
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
