@@ -808,7 +808,8 @@ RLAP_HD void cand_prepare(const Arrays& A, int32_t v, CT& C, int32_t vbase = 0) 
 // (k, w_new) where k is the neighbour j sampled for position p, and its twin becomes the entry j appends to k's column.
 // That is all that happens to d as long as d is neither sampled as a target by j (it would get an appended entry and an
 // Inc: it leaves the predicted order) nor j's last neighbour (its entry dies, Dec: it pre-empts the order) and as long as
-// k is not a neighbour of d already (a multi-edge: the PQ orders send those to the single-vertex path).  Then d's
+// k is not a neighbour of d already (a multi-edge: the PQ orders send those to the single-vertex path) and the new weight
+// is positive (rounding can make it <= 0, and then the rewritten entry is dead: `val > 0`, :252).  Then d's
 // record can be patched from j's sampled record without touching memory; the number of neighbours, hence the number of
 // uniforms d draws, is unchanged.  The twin is recorded as ~(j * CAP + p): resolved from the round's slot table at commit.
 // Sequential form (one thread); returns false when d cannot be patched (the round is cut before it).
@@ -826,6 +827,9 @@ RLAP_HD bool cand_patch(const Arrays& A, CT* cand, int32_t d, int32_t vbase) {
         for (int32_t z = 0; z < J.m; ++z) if (J.e[z].nbr == C.v) p = z;
         if (p < 0 || p == J.m - 1) return false;                        // (last neighbour: :420-432)
         for (int32_t z = 0; z < J.m - 1; ++z) if (J.ksel[z] == p) return false;   // sampled as a target (:394-399)
+        // rounding can leave f > 1 near the end of a long column (wdeg ~ 1e-31): the new weight is then <= 0 and the rewritten
+        // entry is dead for getColumnLength (:252 `val > 0`) -- d has one neighbour less, which only a fresh gather sees
+        if (!(J.e[p].val > 0)) return false;
         const int32_t k = J.e[J.ksel[p]].nbr;
         int32_t qd = -1;
         for (int32_t z = 0; z < C.m; ++z) { if (C.e[z].nbr == J.v) qd = z; if (C.e[z].nbr == k) { C.flags |= CF_DUP; return false; } }

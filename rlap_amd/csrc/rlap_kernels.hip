@@ -1776,6 +1776,7 @@ __device__ __noinline__ bool wave_patch(const Arrays& A, CT* cand, int32_t d, in
         if (__ballot(ks == p) != 0ull) { ok = false; break; }                     // sampled as a target (:394-399)
         const int32_t k = J.e[J.ksel[p]].nbr;
         const double newv = J.e[p].val;
+        if (!(newv > 0)) { ok = false; break; }                                   // dead on arrival (rounding: f > 1), see cand_patch
         if (__ballot(my_nbr == k) != 0ull) { ok = false; dup = true; break; }     // multi-edge: single-vertex path
         const uint64_t qm = __ballot(my_nbr == J.v);
         if (qm == 0ull) { ok = false; break; }

@@ -141,7 +141,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
     std::vector<Cand> cand((size_t)Bsz);
     int64_t why[6] = {0, 0, 0, 0, 0, 0};
     int64_t adjcase[4] = {0, 0, 0, 0};
-    int64_t npatch_try = 0, npatch_ok = 0;
+    int64_t npatch_try = 0, npatch_ok = 0, npatch_dead = 0;
     const int64_t patch_limit = std::getenv("RLAP_MIRROR_PATCH_LIMIT") ? std::atoll(std::getenv("RLAP_MIRROR_PATCH_LIMIT")) : -1;   // diagnostic: only the first N patches
     const bool patching = (A.o_v != OV_COARSEN) && (std::getenv("RLAP_MIRROR_NO_PATCH") == nullptr);   // first dependent candidate of a round: sampled by an earlier one (moves away), last neighbour (Dec), patchable, patch makes a multi-edge
     int64_t single_len = 0, single_gt384 = 0, single_gt384_len = 0, single_max = 0;  // adjacent, big, dup, complex, pre-empted, full
@@ -222,7 +222,11 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
         for (int32_t i = 0; i < Pmax; ++i) {
             if (cand[i].ndep > 0) {
                 ++npatch_try;
-                if ((patch_limit >= 0 && npatch_ok >= patch_limit) || !cand_patch(A, cand.data(), i, G.vbase)) { Pmax = i; Pwhy = (cand[i].flags & CF_DUP) ? 2 : 0; break; }
+                if ((patch_limit >= 0 && npatch_ok >= patch_limit) || !cand_patch(A, cand.data(), i, G.vbase)) {
+                    // (statistics) refused because an earlier candidate's new weight for this one came out <= 0?
+                    for (int32_t q = 0; q < cand[i].ndep; ++q) { const Cand& J = cand[cand[i].dep[q]]; for (int32_t z = 0; z + 1 < J.m; ++z) if (J.e[z].nbr == cand[i].v && !(J.e[z].val > 0)) ++npatch_dead; }
+                    Pmax = i; Pwhy = (cand[i].flags & CF_DUP) ? 2 : 0; break;
+                }
                 ++npatch_ok;
             }
             cand_sample(A, cand[i]);
@@ -380,7 +384,7 @@ static int mirror_batch_impl(const int64_t* row, const int64_t* col, const doubl
         cleanup();
         done += P;
     }
-    if (stats_out) { stats_out[0] = rounds; stats_out[1] = singles; stats_out[2] = contended_total; for (int q = 0; q < 6; ++q) stats_out[3 + q] = why[q]; stats_out[9] = single_len; stats_out[10] = single_gt384; stats_out[11] = single_gt384_len; stats_out[12] = single_max; for (int q = 0; q < 4; ++q) stats_out[13 + q] = adjcase[q]; stats_out[17] = npatch_try; stats_out[18] = npatch_ok; }
+    if (stats_out) { stats_out[0] = rounds; stats_out[1] = singles; stats_out[2] = contended_total; for (int q = 0; q < 6; ++q) stats_out[3 + q] = why[q]; stats_out[9] = single_len; stats_out[10] = single_gt384; stats_out[11] = single_gt384_len; stats_out[12] = single_max; for (int q = 0; q < 4; ++q) stats_out[13 + q] = adjcase[q]; stats_out[17] = npatch_try; stats_out[18] = npatch_ok; stats_out[19] = npatch_dead; }
     return S.finish(nelim, npop, order_out, out, out_rows);
 }
 

@@ -181,3 +181,22 @@ def test_patched_dependent_candidates_equal_sequential_order(host_mirror, o_v, o
                 assert a.shape == b.shape and np.array_equal(a, b), (n, m, B, bc)
                 if o_v == "degree" and bc == 32 and m == 10:
                     assert st[18] > 20, "the patch rule was not exercised"
+
+
+def test_patch_refused_when_the_new_weight_is_not_positive(host_mirror):
+    """Found by the soak run (tests/tools/soak.py, case 3023): late in a long column of a `desc` elimination rounding leaves
+    f > 1, the new weight f(1-f)wdeg is negative (-5e-31) and the rewritten entry is dead for getColumnLength
+    (preconditioner.cc:252, `val > 0`).  A dependent candidate patched with that entry kept a neighbour the reference no longer
+    sees; cand_patch now refuses, the candidate is gathered afresh.  Same graphs, same call as the failing case."""
+    from rlap_amd import graphs
+    n, t, seed = 31749, 28574, 690086160
+    dead = 0
+    for g in (5, 8):
+        ei = graphs.barabasi_albert(n, 5, seed + g).numpy()
+        a, oa = oracle.approximate_cholesky(ei, None, n, t, "degree", "desc", shuffle_seed=seed + g, return_order=True)
+        for B in (4, 32, 128):
+            b, ob, st = _mirror_batch(host_mirror, ei, None, n, t, "degree", "desc", B, seed=seed + g)
+            assert np.array_equal(oa, ob), (g, B)
+            assert a.shape == b.shape and np.array_equal(a, b), (g, B)
+            dead += int(st[19])
+    assert dead > 0, "the case no longer produces a non-positive new weight in front of a dependent candidate"

@@ -301,3 +301,18 @@ def test_schedule_jitter_does_not_change_the_rows(ops, monkeypatch, o_v):
     finally:
         ops.debug_set_jitter(0)
         monkeypatch.delenv("RLAP_BATCH_SHAPE", raising=False)
+
+
+@pytest.mark.parametrize("shape", ["1", "2"])
+def test_dead_new_weight_in_front_of_a_dependent_candidate(ops, monkeypatch, shape):
+    """Soak case 3023 (tests/tools/soak.py): degree/desc on BA(31749, 5), t = 0.9 n.  Rounding makes one new edge weight negative
+    (-5e-31): the reference's `val > 0` filter (preconditioner.cc:252) drops that entry at the next gather, so a dependent
+    candidate must not be patched with it (rlap_core.h::cand_patch).  Two graphs of the failing batch, both workgroup shapes."""
+    from rlap_amd import graphs
+    n, t, seed = 31749, 28574, 690086160
+    monkeypatch.setenv("RLAP_BATCH_SHAPE", shape)
+    for g in (5, 8):
+        ei = graphs.barabasi_albert(n, 5, seed + g)
+        ref = oracle.approximate_cholesky(ei.numpy(), None, n, t, "degree", "desc", shuffle_seed=seed + g)
+        got = ops.approximate_cholesky(ei.cuda(), None, n, t, "degree", "desc", seed=seed + g).numpy()
+        assert_same(got, ref, f"graph {g}, shape {shape}")

@@ -1,7 +1,8 @@
 """Soak run: randomized parity checks of the HIP path against the CPU oracle under the debug perturbations
 (schedule jitter, poisoned workspace), single and batched calls, both workgroup shapes, all (o_v, o_n) modes, unit and tie-free
-weights.  Prints one line per case and a summary; exits non-zero on the first mismatch.
-usage: soak.py SECONDS [SEED]"""
+weights.  Prints a line every ten cases and a summary; exits non-zero on the first mismatch (naming the case number).
+usage: soak.py SECONDS [SEED [FIRST_CASE [REPEAT]]]   -- FIRST_CASE skips the cases before it (same random stream);
+REPEAT > 0 runs only FIRST_CASE, that many times, and counts the mismatches"""
 import os
 import sys
 import time
@@ -10,25 +11,20 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 sys.path.insert(0, _ROOT)
 sys.path.insert(0, os.path.join(_ROOT, "tests"))
 import numpy as np
-import torch
 
-import oracle
-from rlap_amd import graphs, ops
-from util import sym_weights
-
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t_end = time.time() + budget
-n_cases = n_graphs = 0
 O_V = ["degree", "random", "coarsen"]
 O_N = ["asc", "desc", "random"]
-while time.time() < t_end:
-    o_v, o_n = O_V[rs.randint(3)], O_N[rs.randint(3)]
-    jitter = int(rs.choice([0, 0, 2, 5, 9]))
-    poison = int(rs.choice([-1, 0, 255, 90]))
-    shape = str(rs.choice(["", "1", "2"]))
+
+
+def draw(rs):
+    """One case of the stream (every random draw of a case happens here, so a case can be replayed by number)."""
+    c = {}
+    c["o_v"], c["o_n"] = O_V[rs.randint(3)], O_N[rs.randint(3)]
+    c["jitter"] = int(rs.choice([0, 0, 2, 5, 9]))
+    c["poison"] = int(rs.choice([-1, 0, 255, 90]))
+    c["shape"] = str(rs.choice(["", "1", "2"]))
     batched = rs.rand() < 0.5
-    weighted = rs.rand() < 0.35
+    c["weighted"] = bool(rs.rand() < 0.35)
     kind = rs.randint(4)
     if kind == 0:
         n, m = int(rs.randint(40, 400)), int(rs.randint(1, 30))
@@ -43,44 +39,89 @@ while time.time() < t_end:
     if batched and n * G > 600000:
         G = max(2, 600000 // n)
     frac = float(rs.choice([0.1, 0.5, 0.5, 0.9, 1.0]))
-    seed = int(rs.randint(1 << 30))
-    if shape:
-        os.environ["RLAP_BATCH_SHAPE"] = shape
+    c["seed"] = int(rs.randint(1 << 30))
+    c["n"], c["m"], c["G"], c["t"], c["batched"] = n, m, G, int(frac * n), batched
+    c["check"] = list(range(G)) if G <= 8 else sorted(set(rs.randint(0, G, size=6).tolist()))
+    return c
+
+
+def describe(c):
+    return (f"{c['o_v']}/{c['o_n']} n={c['n']} m={c['m']} G={c['G']} t={c['t']} weighted={c['weighted']} jitter={c['jitter']} "
+            f"poison={c['poison']} shape={c['shape'] or 'auto'} seed={c['seed']}")
+
+
+def run_case(c, check_all=False):
+    """Returns the list of graphs of the case whose rows differ from the oracle's."""
+    import torch
+    import oracle
+    from rlap_amd import graphs, ops
+    from util import sym_weights
+    n, G, t, seed, o_v, o_n = c["n"], c["G"], c["t"], c["seed"], c["o_v"], c["o_n"]
+    if c["shape"]:
+        os.environ["RLAP_BATCH_SHAPE"] = c["shape"]
     else:
         os.environ.pop("RLAP_BATCH_SHAPE", None)
-    ops.debug_set_jitter(jitter)
-    ops.debug_set_poison(poison)
-    eis = [graphs.barabasi_albert(n, m, seed + g) for g in range(G)]
-    ws = [sym_weights(e.numpy(), n, seed + 7 * g) if weighted else None for g, e in enumerate(eis)]
+    ops.debug_set_jitter(c["jitter"])
+    ops.debug_set_poison(c["poison"])
+    eis = [graphs.barabasi_albert(n, c["m"], seed + g) for g in range(G)]
+    ws = [sym_weights(e.numpy(), n, seed + 7 * g) if c["weighted"] else None for g, e in enumerate(eis)]
     perms = [np.random.RandomState(seed + g).permutation(n) for g in range(G)]
-    t = int(frac * n)
-    desc = f"{o_v}/{o_n} n={n} m={m} G={G} t={t} weighted={weighted} jitter={jitter} poison={poison} shape={shape or 'auto'}"
-    if batched:
+    bad = []
+    if c["batched"]:
         big, node_ptr = graphs.batch_disjoint(eis, [n] * G)
-        w = None if not weighted else torch.from_numpy(np.concatenate(ws))
+        w = None if not c["weighted"] else torch.from_numpy(np.concatenate(ws))
         perm = torch.from_numpy(np.concatenate(perms)) if o_v == "random" else None
         sc, rp = ops.approximate_cholesky_batched(big.cuda(), None if w is None else w.cuda(), node_ptr, [t] * G, o_v, o_n, perm=perm, seed=seed)
         sc = sc.cpu().numpy()
-        check = range(G) if G <= 8 else sorted(set(rs.randint(0, G, size=6).tolist()))
-        for g in check:
+        for g in (range(G) if check_all else c["check"]):
             ref = oracle.approximate_cholesky(eis[g].numpy(), ws[g], n, t, o_v, o_n, perm=perms[g], shuffle_seed=seed + g)
             got = sc[int(rp[g]):int(rp[g + 1])].copy()
             got[:, :2] -= g * n
             if got.shape != ref.shape or not np.array_equal(got, ref):
-                print("MISMATCH", desc, "graph", g, got.shape, ref.shape, flush=True)
-                sys.exit(1)
-            n_graphs += 1
+                bad.append((g, got.shape, ref.shape))
     else:
-        got = ops.approximate_cholesky(eis[0].cuda(), None if not weighted else torch.from_numpy(ws[0]).cuda(), n, t, o_v, o_n,
+        got = ops.approximate_cholesky(eis[0].cuda(), None if not c["weighted"] else torch.from_numpy(ws[0]).cuda(), n, t, o_v, o_n,
                                        perm=torch.from_numpy(perms[0]) if o_v == "random" else None, seed=seed).numpy()
         ref = oracle.approximate_cholesky(eis[0].numpy(), ws[0], n, t, o_v, o_n, perm=perms[0], shuffle_seed=seed)
         if got.shape != ref.shape or not np.array_equal(got, ref):
-            print("MISMATCH", desc, got.shape, ref.shape, flush=True)
+            bad.append((0, got.shape, ref.shape))
+    return bad
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    repeat = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    for _ in range(first):
+        draw(rs)
+    if repeat > 0:
+        c = draw(rs)
+        print("case", first, describe(c), flush=True)
+        n_bad = 0
+        for r in range(repeat):
+            bad = run_case(c, check_all=True)
+            n_bad += bool(bad)
+            print(f"  run {r}: {'ok' if not bad else bad}", flush=True)
+        print(f"{n_bad} of {repeat} runs differ from the oracle")
+        sys.exit(1 if n_bad else 0)
+    t_end = time.time() + budget
+    n_cases, n_graphs = first, 0
+    while time.time() < t_end:
+        c = draw(rs)
+        bad = run_case(c)
+        if bad:
+            print("MISMATCH case", n_cases, describe(c), bad, flush=True)
             sys.exit(1)
-        n_graphs += 1
-    n_cases += 1
-    if n_cases % 10 == 0:
-        print(f"[{n_cases} cases, {n_graphs} graphs checked] last: {desc}", flush=True)
-ops.debug_set_jitter(0)
-ops.debug_set_poison(-1)
-print(f"soak ok: {n_cases} cases, {n_graphs} graphs bit-exact against the oracle in {budget:.0f} s")
+        n_graphs += len(c["check"])
+        n_cases += 1
+        if n_cases % 10 == 0:
+            print(f"[{n_cases} cases, {n_graphs} graphs checked] last: {describe(c)}", flush=True)
+    from rlap_amd import ops
+    ops.debug_set_jitter(0)
+    ops.debug_set_poison(-1)
+    print(f"soak ok: cases {first}..{n_cases - 1}, {n_graphs} graphs bit-exact against the oracle in {budget:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
