@@ -66,7 +66,7 @@ struct Setup {
             ocur[key[orig[i]]] = i; oend[key[orig[i]]] = j;
             i = j;
         }
-        int64_t rng_len = (int64_t)nnz * 4 + 1024;
+        int64_t rng_len = std::max<int64_t>((int64_t)nnz * 4 + 1024, (int64_t)pool_slots);   // (a draw per appended entry at most)
         rng.resize((size_t)rng_len);
         {
             std::mt19937_64 g;

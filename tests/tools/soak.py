@@ -41,12 +41,59 @@ def draw(rs):
     frac = float(rs.choice([0.1, 0.5, 0.5, 0.9, 1.0]))
     c["seed"] = int(rs.randint(1 << 30))
     c["n"], c["m"], c["G"], c["t"], c["batched"] = n, m, G, int(frac * n), batched
+    c["topo"] = str(rs.choice(["ba", "ba", "ba", "hub", "er", "grid", "cliques"]))
     c["check"] = list(range(G)) if G <= 8 else sorted(set(rs.randint(0, G, size=6).tolist()))
     return c
 
 
+def make_graph(c, g):
+    """Graph g of case c: (2,E) int64 numpy, symmetric and coalesced.  Topologies besides BA(n, m): `hub` = BA plus one vertex
+    joined to a third of the others (long columns: the big single-vertex paths), `er` = uniform random pairs (isolated and
+    degree-1 vertices), `grid` = 2-D grid of about n vertices, `cliques` = ring of (m+2)-cliques (multi-edges from the first
+    elimination on)."""
+    from rlap_amd import graphs
+    from util import symmetrize
+    n, m, seed = c["n"], c["m"], c["seed"] + g
+    rs = np.random.RandomState(seed % (1 << 31))
+    topo = c.get("topo", "ba")
+    if topo == "ba":
+        return graphs.barabasi_albert(n, m, seed).numpy()
+    if topo == "hub":
+        ei = graphs.barabasi_albert(n, m, seed).numpy()
+        h = int(rs.randint(n))
+        others = np.flatnonzero(rs.rand(n) < 0.33)
+        others = others[others != h].astype(np.int64)
+        return symmetrize(np.concatenate([ei[0], np.full(others.size, h, dtype=np.int64)]), np.concatenate([ei[1], others]), n)
+    if topo == "er":
+        k = max(1, n * m // 2)
+        a, b = rs.randint(0, n, size=k).astype(np.int64), rs.randint(0, n, size=k).astype(np.int64)
+        keep = a != b
+        if not keep.any():
+            a, b, keep = np.array([0], dtype=np.int64), np.array([1], dtype=np.int64), np.array([True])
+        return symmetrize(a[keep], b[keep], n)
+    if topo == "grid":
+        h = max(2, int(np.sqrt(n)))
+        w = max(2, n // h)
+        idx = np.arange(h * w).reshape(h, w)
+        a = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()]).astype(np.int64)
+        b = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()]).astype(np.int64)
+        return symmetrize(a, b, n)          # (vertices h*w .. n-1 stay isolated)
+    q = min(m + 2, n)                       # cliques
+    nq = n // q
+    a, b = [], []
+    iu, ju = np.triu_indices(q, 1)
+    for z in range(nq):
+        a.append(z * q + iu)
+        b.append(z * q + ju)
+        a.append(np.array([z * q + q - 1]))
+        b.append(np.array([((z + 1) % nq) * q]))
+    a, b = np.concatenate(a).astype(np.int64), np.concatenate(b).astype(np.int64)
+    keep = a != b
+    return symmetrize(a[keep], b[keep], n)
+
+
 def describe(c):
-    return (f"{c['o_v']}/{c['o_n']} n={c['n']} m={c['m']} G={c['G']} t={c['t']} weighted={c['weighted']} jitter={c['jitter']} "
+    return (f"{c.get('topo', 'ba')} {c['o_v']}/{c['o_n']} n={c['n']} m={c['m']} G={c['G']} t={c['t']} weighted={c['weighted']} jitter={c['jitter']} "
             f"poison={c['poison']} shape={c['shape'] or 'auto'} seed={c['seed']}")
 
 
@@ -63,7 +110,7 @@ def run_case(c, check_all=False):
         os.environ.pop("RLAP_BATCH_SHAPE", None)
     ops.debug_set_jitter(c["jitter"])
     ops.debug_set_poison(c["poison"])
-    eis = [graphs.barabasi_albert(n, c["m"], seed + g) for g in range(G)]
+    eis = [torch.from_numpy(make_graph(c, g)) for g in range(G)]
     ws = [sym_weights(e.numpy(), n, seed + 7 * g) if c["weighted"] else None for g, e in enumerate(eis)]
     perms = [np.random.RandomState(seed + g).permutation(n) for g in range(G)]
     bad = []
