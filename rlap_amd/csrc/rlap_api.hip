@@ -391,8 +391,10 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     {
         Fills F;
         F.add(W.scal.p, sizeof(Scalars) / 4, 0);
-        F.add(W.bs_cnt.p, bucket_total, 0); F.add(W.bs_alloc.p, bucket_total, 0);
-        F.add(W.ocur.p, bucket_total, 0); F.add(W.oend.p, bucket_total, 0);
+        if (c.o_v != OV_RANDOM) {   // the bucket stacks and the never-moved lists: PQ orders only
+            F.add(W.bs_cnt.p, bucket_total, 0); F.add(W.bs_alloc.p, bucket_total, 0);
+            F.add(W.ocur.p, bucket_total, 0); F.add(W.oend.p, bucket_total, 0);
+        }
         F.add(W.bs_pool_top.p, 1, 0);
         F.add(W.batch_pos.p, N, -1);
         F.add(W.ext.as<int32_t>() + S, 1, 0); F.add(W.cnt.as<int32_t>() + S, 1, 0);
@@ -467,13 +469,13 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     const unsigned gbits = bits_for((uint64_t)(G > 0 ? G - 1 : 0));
     hipLaunchKernelGGL(k_pq_init, dim3(nblk(N, 256)), dim3(256), 0, s, W.colptr.as<int32_t>(), W.vgraph.as<int32_t>(), (int32_t)N, W.vrec.as<VRec>(),
                        W.skey0.as<uint64_t>(), W.sval0.as<uint32_t>());
-    {
+    if (c.o_v != OV_RANDOM) {   // (o_v = random has no queue: k_pq_init's vertex records are all it needs)
         // key = graph << 32 | degree: only the bits that can be set take part in the sort
         int rc = sort_pairs(h, ST, W.skey0.as<uint64_t>(), W.skey1.as<uint64_t>(), W.sval0.as<uint32_t>(), W.orig_order.as<uint32_t>(), N, 0, 32 + gbits);
         if (rc) return rc;
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, W.orig_order.as<uint32_t>(), W.vrec.as<VRec>(), W.vgraph.as<int32_t>(),
+                           W.gd_d.as<GraphDesc>(), (int32_t)N, W.ocur.as<int32_t>(), W.oend.as<int32_t>(), W.origpos.as<int32_t>());
     }
-    hipLaunchKernelGGL(k_bucket_bounds, dim3(nblk(N, 256)), dim3(256), 0, s, W.orig_order.as<uint32_t>(), W.vrec.as<VRec>(), W.vgraph.as<int32_t>(),
-                       W.gd_d.as<GraphDesc>(), (int32_t)N, W.ocur.as<int32_t>(), W.oend.as<int32_t>(), W.origpos.as<int32_t>());
 
     // ---------------- o_v = random: the node_id vector ----------------
     const int64_t* d_perm = c.d_perm;

@@ -3995,6 +3995,11 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
     // long columns: whole column in LDS, one single-wave workgroup each; longer than the LDS record array (hubs of
     // weighted graphs): records in global scratch, a few workgroups
     // (one workgroup of 8 waves per CU at ~156 KB of LDS: the few columns beyond MIDCAP slots; the tier below: 4 waves, three to a CU)
+    // (the <=512 tier goes first on the first side stream: the 8-wave kernel behind it needs a whole CU's LDS per workgroup and waits for
+    // one to drain anyway -- config 5 has no such column and the kernel sat there for 4.7 ms; on the main stream this tier was the end of
+    // the longest chain, <=32 -> <=64 -> <=512: 4.8 ms)
+    unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
+    hipLaunchKernelGGL((k_sc_merge_t<SCAP, 192>), dim3(g2), dim3(64), 0, s1, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + 2 * (size_t)S, counts + 2);
     hipLaunchKernelGGL((k_sc_merge_mw<8>), dim3(512), dim3(512), MW_BIG_LDS_BYTES, s1, A, gd, vgraph, order, ext, tmp_off, lists + 3 * (size_t)S, counts + 3,
                        tmp_nbr, tmp_val, cnt_out, live_total, (int32_t)BIGCAP, (int32_t)MW_BIG_QCAP);
     hipLaunchKernelGGL((k_sc_merge_mw<4>), dim3(1024), dim3(256), MW_MID_LDS_BYTES, s2, A, gd, vgraph, order, ext, tmp_off, lists + 6 * (size_t)S, counts + 6,
@@ -4004,15 +4009,12 @@ void launch_sc_merge(const ScLaunch& X, const Arrays& A, const GraphDesc* gd, co
     hipLaunchKernelGGL(k_sc_merge_huge, dim3(NHUGE), dim3(64), 0, s1, A, gd, vgraph, order, ext, tmp_off, lists + 4 * (size_t)S, counts + 4,
                        tmp_nbr, tmp_val, cnt_out, live_total, hugelists, SS.rec, SS.top, SS.cap, SS.flags);
     unsigned g1 = (unsigned)(S < 256 * 16 * 8 ? S : 256 * 16 * 8);
-    unsigned g2 = (unsigned)(S < 256 * 6 * 16 ? S : 256 * 6 * 16);
     hipLaunchKernelGGL((k_sc_merge_t<192, 64>), dim3(g1), dim3(64), 0, s2, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + (size_t)S, counts + 1);
     unsigned gh = (unsigned)(S < 256 * 32 * 4 ? (S + 1) / 2 : 256 * 32 * 4);
     if (gh == 0) gh = 1;
     hipLaunchKernelGGL(k_sc_merge_half, dim3(gh), dim3(64), 0, stream, A, gd, vgraph, order, tmp_off, tmp_nbr, tmp_val, cnt_out, live_total, lists + 5 * (size_t)S, counts + 5, lists, counts);
     unsigned g0 = (unsigned)(S < 256 * 32 * 4 ? S : 256 * 32 * 4);
     hipLaunchKernelGGL((k_sc_merge_t<64, -1>), dim3(g0), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists, counts);
-    // (the <=512 tier follows on the main stream: the second side stream is the longest chain otherwise -- config 5: 4.8 ms of kernels against 2.7 here)
-    hipLaunchKernelGGL((k_sc_merge_t<SCAP, 192>), dim3(g2), dim3(64), 0, stream, A, gd, vgraph, order, ext, tmp_off, S, tmp_nbr, tmp_val, cnt_out, SS, live_total, lists + 2 * (size_t)S, counts + 2);
     if (fork) {
         (void)hipEventRecord(X.ev[1], s1);
         (void)hipEventRecord(X.ev[2], s2);

@@ -98,6 +98,15 @@ def _handle(device: torch.device):
     return lib, hobj.ptr
 
 
+def _trim(out: torch.Tensor, rows: int) -> torch.Tensor:
+    """The first `rows` rows of the (E,3) result buffer.  A view keeps the whole buffer alive, a copy costs a pass over the
+    result (0.6 ms for the 1.5 GB of the 1024-graph batch): copy only when the view would pin more than a third on top."""
+    res = out[:rows]
+    if 4 * rows < 3 * out.shape[0]:
+        res = res.clone()
+    return res
+
+
 def _run(hobj, dev, E: int, n_total: int, G: int, symmetrize: bool, call, st):
     """One op call inside torch-owned memory: size the arena for (E, n_total, G), call, and when the library reports
     that it wants more (a growth limit was met and the repeated attempt is of a larger size class) grow and call again."""
@@ -230,9 +239,9 @@ def approximate_cholesky(
         if rc != 0:
             _raise(rc)
         last_stats = st.as_dict()
-        res = out[: rows.value]
+        res = _trim(out, rows.value)
     if return_device is None or return_device == "same":
-        return res.clone() if res.shape[0] != out.shape[0] else res
+        return res
     return res.to(return_device)
 
 
@@ -287,9 +296,7 @@ def approximate_cholesky_from_edges(
         if rc != 0:
             _raise(rc)
         last_stats = st.as_dict()
-        res = out[: rows.value]
-        if rows.value != out.shape[0]:
-            res = res.clone()
+        res = _trim(out, rows.value)
     if return_device is not None and return_device != "same":
         res = res.to(return_device)
     return res, int(nn.value)
@@ -346,9 +353,7 @@ def approximate_cholesky_batched(
         if rc != 0:
             _raise(rc)
         last_stats = st.as_dict()
-        res = out[: int(row_ptr[-1])]
-        if res.shape[0] != out.shape[0]:
-            res = res.clone()   # do not pin the (E,3) buffer behind a shorter view
+        res = _trim(out, int(row_ptr[-1]))
     if return_device is not None and return_device != "same":
         res = res.to(return_device)
     return res, row_ptr

@@ -101,6 +101,14 @@ struct Setup {
     // output phase (shared by both drivers)
     int finish(int64_t nelim, int64_t npop, int64_t* order_out, double** out, int64_t* out_rows) {
         std::vector<double> res;
+        if (std::getenv("RLAP_MIRROR_EXT_HIST")) {   // diagnostic: slots per surviving column (what the output pass's tiers are sized by) and live entries
+            std::vector<char> gone((size_t)n, 0);
+            if (order_out) for (int64_t q = 0; q < npop; ++q) gone[order_out[q]] = 1;
+            for (int64_t v = 0; v < n; ++v) if (!gone[v]) {
+                int32_t ext = (A.colptr[v + 1] - A.colptr[v]) + A.vr[v].app_cnt;
+                if (ext > 512) std::fprintf(stderr, "ext %d live %d\n", ext, serial_gather(A, (int32_t)v, B, cap));
+            }
+        }
         for (int64_t q = nelim; q < n; ++q) {
             int32_t v = (A.o_v == OV_RANDOM) ? (int32_t)perm_l[n - 1 - q] : pq_pop(A, G);
             if (order_out) order_out[npop] = v;
@@ -441,6 +449,58 @@ int mirror_approx_chol(const int64_t* row, const int64_t* col, const double* w, 
 
 // stats_out: [0] rounds, [1] single-vertex fallbacks, [2] contended targets, [3..8] what ended the rounds
 // (adjacent candidate, long column, multi-edge, complex key, pre-empting move, nothing).
+// Schedule model of the dataflow design of DESIGN.md section 8 item 7, for o_v = random (the order is known in advance): the
+// sequential elimination is run once and, beside it, an event simulation for each worker count in workers[]: the next position
+// of the order is claimed by the wave that is free first; it can gather once every EARLIER vertex that was adjacent to it when
+// that one was eliminated has committed (touch[]); its neighbour count is published cost[0] + cost[1]*len later; the uniform
+// offsets are a chain over the published counts (cost[4] per link); sampling + commit take cost[2] + cost[3]*len.  No
+// speculation is modelled (a wave that has claimed a blocked position waits).  out[k] = makespan (same unit as cost[]) for
+// workers[k]; out[nW + 0..3] = dependency levels (longest chain, in vertices), critical path (unbounded workers), mean and
+// maximum gathered length.
+int mirror_flow_model(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t, int o_n,
+                      const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t nW, const int32_t* workers,
+                      const double* cost, double* out) {
+    Setup S;
+    S.build(row, col, w, E, n, t, OV_RANDOM, o_n, perm, shuffle_seed, pool_slots);
+    int64_t nelim = std::min<int64_t>(t, n - 1);
+    if (nelim < 0) nelim = 0;
+    const int K = nW + 1;                                   // last model: unbounded workers
+    std::vector<std::vector<double>> touch((size_t)K, std::vector<double>((size_t)n, 0.0));
+    std::vector<std::vector<double>> freeq((size_t)nW);      // min-heaps of the waves' free times
+    for (int k = 0; k < nW; ++k) freeq[k].assign((size_t)workers[k], 0.0);
+    std::vector<double> off_prev((size_t)K, 0.0), makespan((size_t)K, 0.0);
+    std::vector<int32_t> levtouch((size_t)n, 0);
+    int32_t maxlev = 0, maxlen = 0;
+    double sumlen = 0;
+    for (int64_t e1 = 1; e1 <= nelim; ++e1) {
+        int32_t v = (int32_t)S.perm_l[n - e1];
+        int32_t len = serial_gather(S.A, v, S.B, S.cap);
+        std::vector<int32_t> nb(S.B.a_nbr, S.B.a_nbr + len);
+        sumlen += len; if (len > maxlen) maxlen = len;
+        int32_t lev = levtouch[v] + 1;
+        if (lev > maxlev) maxlev = lev;
+        for (int32_t x : nb) if (levtouch[x] < lev) levtouch[x] = lev;
+        const double tp = cost[0] + cost[1] * len, tc = cost[2] + cost[3] * len;
+        for (int k = 0; k < K; ++k) {
+            double wf = 0;
+            if (k < nW) { std::pop_heap(freeq[k].begin(), freeq[k].end(), std::greater<double>()); wf = freeq[k].back(); }
+            const double start = std::max(wf, touch[k][v]);
+            const double pub = start + tp;
+            const double off = std::max(pub, off_prev[k]) + cost[4];
+            off_prev[k] = off;
+            const double fin = off + tc;
+            if (k < nW) { freeq[k].back() = fin; std::push_heap(freeq[k].begin(), freeq[k].end(), std::greater<double>()); }
+            for (int32_t x : nb) if (touch[k][x] < fin) touch[k][x] = fin;
+            if (fin > makespan[k]) makespan[k] = fin;
+        }
+        int rc = serial_eliminate(S.A, S.G, S.B, S.cap, v, e1);
+        if (rc) return rc;
+    }
+    for (int k = 0; k < nW; ++k) out[k] = makespan[k];
+    out[nW] = maxlev; out[nW + 1] = makespan[nW]; out[nW + 2] = nelim ? sumlen / (double)nelim : 0; out[nW + 3] = maxlen;
+    return 0;
+}
+
 int mirror_approx_chol_batch(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t,
                              int o_v, int o_n, const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t Bsz,
                              double** out, int64_t* out_rows, int64_t* order_out, int64_t* stats_out) {
