@@ -42,6 +42,9 @@ def draw(rs):
     c["seed"] = int(rs.randint(1 << 30))
     c["n"], c["m"], c["G"], c["t"], c["batched"] = n, m, G, int(frac * n), batched
     c["topo"] = str(rs.choice(["ba", "ba", "ba", "hub", "er", "grid", "cliques"]))
+    # single unweighted PQ-order calls: a quarter goes through the fused entry point (one direction of every edge, shuffled;
+    # num_nodes and num_remove found on the device)
+    c["from_edges"] = bool(rs.rand() < 0.25) and not batched and not c["weighted"] and c["o_v"] != "random"
     c["check"] = list(range(G)) if G <= 8 else sorted(set(rs.randint(0, G, size=6).tolist()))
     return c
 
@@ -94,7 +97,7 @@ def make_graph(c, g):
 
 def describe(c):
     return (f"{c.get('topo', 'ba')} {c['o_v']}/{c['o_n']} n={c['n']} m={c['m']} G={c['G']} t={c['t']} weighted={c['weighted']} jitter={c['jitter']} "
-            f"poison={c['poison']} shape={c['shape'] or 'auto'} seed={c['seed']}")
+            f"poison={c['poison']} shape={c['shape'] or 'auto'} seed={c['seed']}" + (" from_edges" if c.get("from_edges") else ""))
 
 
 def run_case(c, check_all=False):
@@ -126,6 +129,18 @@ def run_case(c, check_all=False):
             got[:, :2] -= g * n
             if got.shape != ref.shape or not np.array_equal(got, ref):
                 bad.append((g, got.shape, ref.shape))
+    elif c.get("from_edges"):
+        e = eis[0].numpy()
+        up = e[:, e[0] < e[1]]
+        up = up[:, np.random.RandomState(seed).permutation(up.shape[1])]
+        n_ref = int(e.max()) + 1                       # (isolated top ids drop out: the reference's max + 1 rule)
+        frac = t / n
+        got, nn = ops.approximate_cholesky_from_edges(torch.from_numpy(np.ascontiguousarray(up)).cuda(), None, None, None, o_v, o_n,
+                                                      remove_frac=frac, symmetrize=True, seed=seed)
+        ref = oracle.approximate_cholesky(e, None, n_ref, int(frac * n_ref), o_v, o_n, shuffle_seed=seed)
+        got = got.cpu().numpy()
+        if nn != n_ref or got.shape != ref.shape or not np.array_equal(got, ref):
+            bad.append((0, got.shape, ref.shape))
     else:
         got = ops.approximate_cholesky(eis[0].cuda(), None if not c["weighted"] else torch.from_numpy(ws[0]).cuda(), n, t, o_v, o_n,
                                        perm=torch.from_numpy(perms[0]) if o_v == "random" else None, seed=seed).numpy()
