@@ -30,4 +30,4 @@ for n, m in ((2708, 2), (100, 50), (4096, 8), (19717, 2)):
             ref = oracle.approximate_cholesky(ei.numpy(), None, n, n // 2, o_v, "asc", perm=perm)
         cpu = (time.perf_counter() - t0) / 5
         ok = np.array_equal(out.cpu().numpy(), ref)
-        print(f"BA({n},{m}) {o_v}/asc: GPU {gpu*1e3:.2f} ms per call (setup {st['ms_setup']:.2f} / elim {st['ms_elim']:.2f} / output {st['ms_output']:.2f}), CPU port {cpu*1e3:.2f} ms, bit-exact={ok}")
+        print(f"BA({n},{m}) {o_v}/asc: GPU {gpu*1e3:.2f} ms per call (setup {st['ms_setup']:.2f} / elim {st['ms_elim']:.2f} / output {st['ms_output']:.2f}), CPU port {cpu*1e3:.2f} ms, bit-exact={ok}; rounds {st.get('n_rounds')} singles {st.get('n_singles')}")
