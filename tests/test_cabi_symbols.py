@@ -80,3 +80,17 @@ def test_elimination_kernels_keep_their_register_and_lds_budget(tmp_path):
             assert k["lds"] <= 40960, (name, k)
         else:
             assert k["lds"] <= 163840, (name, k)
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The boundary is a C ABI: include/rlap_hip.h compiles as pedantic C99 with nothing but <stdint.h>/<stddef.h>, and a caller
+    written in C (examples/cabi_caller.c: hipMalloc + the workspace contract + one call) compiles and links against the library."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "rlap_hip.h"\nint main(void) { rlap_handle h = 0; rlap_stats s; (void)h; (void)s; return RLAP_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(root, "examples", "cabi_caller.c"), "-o", str(tmp_path / "cabi_caller"),
+                           "-L", os.path.join(root, "rlap_amd"), "-lrlap_hip", "-L", "/opt/rocm/lib", "-lamdhip64"])

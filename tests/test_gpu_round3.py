@@ -316,3 +316,23 @@ def test_dead_new_weight_in_front_of_a_dependent_candidate(ops, monkeypatch, sha
         ref = oracle.approximate_cholesky(ei.numpy(), None, n, t, "degree", "desc", shuffle_seed=seed + g)
         got = ops.approximate_cholesky(ei.cuda(), None, n, t, "degree", "desc", seed=seed + g).numpy()
         assert_same(got, ref, f"graph {g}, shape {shape}")
+
+
+@pytest.mark.parametrize("mode", [(1, 0, "degree", "asc"), (2, 0, "coarsen", "asc"), (1, 2, "degree", "random")])
+def test_c_caller_of_the_abi_matches_the_oracle(ops, tmp_path, mode):
+    """examples/cabi_caller.c: a program in C (hipMalloc, rlap_workspace_query / rlap_set_workspace, rlap_approx_chol; no torch in the
+    process) -- its rows, read back from the file it writes, against the oracle on the same graph."""
+    import subprocess
+    from rlap_amd import graphs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "cabi_caller")
+    assert os.path.exists(exe), "examples/cabi_caller is built by __graft_entry__.build()"
+    ov, on, o_v, o_n = mode
+    n, m, seed = 6000, 5, 17
+    out = tmp_path / "rows.bin"
+    r = subprocess.run([exe, str(n), str(m), str(seed), str(n // 2), str(ov), str(on), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.fromfile(out, dtype=np.float64).reshape(-1, 3)
+    ei = graphs.barabasi_albert(n, m, seed).numpy()
+    ref = oracle.approximate_cholesky(ei, None, n, n // 2, o_v, o_n, shuffle_seed=seed)
+    assert_same(got, ref, f"C caller {o_v}/{o_n}: {r.stdout.strip()}")
