@@ -336,3 +336,28 @@ def test_c_caller_of_the_abi_matches_the_oracle(ops, tmp_path, mode):
     ei = graphs.barabasi_albert(n, m, seed).numpy()
     ref = oracle.approximate_cholesky(ei, None, n, n // 2, o_v, o_n, shuffle_seed=seed)
     assert_same(got, ref, f"C caller {o_v}/{o_n}: {r.stdout.strip()}")
+
+
+def test_soak_slice(ops):
+    """The first cases of the soak stream (tests/tools/soak.py, seed 2024): random mode / topology (BA, hub, random pairs, grid, clique
+    ring) / size / batch / weights / workgroup shape / jitter / poison / fused entry point, every result against the oracle.  The long
+    runs of that tool found the dead-new-weight case; this slice keeps the net in the suite."""
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import soak
+    saved = os.environ.get("RLAP_BATCH_SHAPE")
+    rs = np.random.RandomState(2024)
+    try:
+        for k in range(70):
+            c = soak.draw(rs)
+            bad = soak.run_case(c)
+            assert not bad, f"case {k}: {soak.describe(c)}: {bad}"
+    finally:
+        ops.debug_set_jitter(0)
+        ops.debug_set_poison(-1)
+        if saved is None:
+            os.environ.pop("RLAP_BATCH_SHAPE", None)
+        else:
+            os.environ["RLAP_BATCH_SHAPE"] = saved
