@@ -41,7 +41,7 @@ for r in rows:
     a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
 tot = sum(v[1] for v in agg.values())
 with open(os.path.join(PROF, f"{rnd}_kernel_stats_bench_c3.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (4 calls of the op; rocPRIM template names shortened)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (7 calls of the op: 1 warm-up + 3 timed + 3 of the unsorted-input line; rocPRIM template names shortened)\n")
     f.write("kernel,calls,total_ms,avg_us,percent\n")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         f.write(f"{k},{c},{t/1e6:.3f},{t/c/1e3:.1f},{100*t/tot:.3f}\n")
@@ -55,7 +55,7 @@ if hits_c5:
         a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
     tot5 = sum(v[1] for v in agg5.values())
     with open(os.path.join(PROF, f"{rnd}_kernel_stats_bench_c5.csv"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c5 --steps 5 --warmup 2 --no-cpu-baseline (7 calls of the op: 1024 x BA(4096,8), o_v=random; measured at {os.environ.get('RLAP_COMMIT', '?')}; rocPRIM template names shortened)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload c5 --steps 5 --warmup 2 --no-cpu-baseline (7 calls of the 1024-graph batch + 7 of its 128-graph shard: BA(4096,8), o_v=random; measured at {os.environ.get('RLAP_COMMIT', '?')}; rocPRIM template names shortened)\n")
         f.write("kernel,calls,total_ms,avg_us,percent\n")
         for k, (c, t) in sorted(agg5.items(), key=lambda kv: -kv[1][1]):
             f.write(f"{k},{c},{t/1e6:.3f},{t/c/1e3:.1f},{100*t/tot5:.3f}\n")
