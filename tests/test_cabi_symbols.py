@@ -94,3 +94,17 @@ def test_header_is_plain_c99(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
                            os.path.join(root, "examples", "cabi_caller.c"), "-o", str(tmp_path / "cabi_caller"),
                            "-L", os.path.join(root, "rlap_amd"), "-lrlap_hip", "-L", "/opt/rocm/lib", "-lamdhip64"])
+
+
+def test_size_query_rejects_what_int32_slot_ids_cannot_hold():
+    """rlap_workspace_bytes is host arithmetic up to the point where it asks rocPRIM for its temporary sizes: the range checks in front
+    of that answer without a GPU -- 2^31 directed entries (slot ids are int32: RLAP_E_TOO_LARGE), a negative count (RLAP_E_BAD_ARG)."""
+    import ctypes
+    from rlap_amd import _lib
+    lib = _lib.load()
+    b, r = ctypes.c_size_t(), ctypes.c_int64()
+    q = lambda E, n, G: lib.rlap_workspace_bytes(ctypes.c_int64(E), ctypes.c_int64(n), ctypes.c_int64(G), 0, ctypes.byref(b), ctypes.byref(r))
+    assert q(1 << 31, 1000, 1) == 9      # RLAP_E_TOO_LARGE
+    assert q(1000, 1 << 30, 1) == 9
+    assert q(-5, 10, 1) == 3             # RLAP_E_BAD_ARG
+    assert lib.rlap_status_string(9).decode() == "problem exceeds int32 slot ids"
