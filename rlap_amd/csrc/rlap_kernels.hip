@@ -975,6 +975,17 @@ __device__ __forceinline__ bool group_sort(double& key, int& idx, const int n, c
     return !fail;
 }
 
+// wave_sort64 out of line for the round loop of the 64-slot kernels: the sort's registers are then not part of the round's pressure
+struct WS64 { double key; int idx; int pos; int ok; };
+template <bool DESC>
+__device__ __noinline__ WS64 wave_sort64_call(double key, int idx, const int n, const int lane, int32_t* tmp) {
+    ASSUME_LDS(tmp);
+    int pos = lane;
+    const bool ok = wave_sort64<DESC>(key, idx, n, lane, tmp, &pos);
+    WS64 r; r.key = key; r.idx = idx; r.pos = pos; r.ok = ok ? 1 : 0;
+    return r;
+}
+
 struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key < y.key; } };
 struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
 
@@ -2513,7 +2524,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                             const int src = lane < nlive ? tmp[144 + lane] : 0;
                             double key = (double)__shfl(me, src);
                             int idx = src, pos = lane;
-                            const bool ok = wave_sort64<false>(key, idx, nlive, lane, tmp, &pos);
+                            const WS64 wr = wave_sort64_call<false>(key, idx, nlive, lane, tmp);
+                            key = wr.key; idx = wr.idx; pos = wr.pos;
+                            const bool ok = wr.ok != 0;
                             WAVE_SYNC();
                             if (lane < nlive) tmp[144 + idx] = pos;
                             WAVE_SYNC();
@@ -2635,7 +2648,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     if ((fl & (CF_BIG | CF_DUP | CF_READY)) || !(m > 16 && (fl & CF_TIE) && (fl & CF_NEQ))) continue;
                     double key = lane < m ? C.e[lane].aux : 0.0;
                     int idx = lane, pos = lane;
-                    const bool ok = desc ? wave_sort64<true>(key, idx, m, lane, tmp, &pos) : wave_sort64<false>(key, idx, m, lane, tmp, &pos);
+                    const WS64 wr = desc ? wave_sort64_call<true>(key, idx, m, lane, tmp) : wave_sort64_call<false>(key, idx, m, lane, tmp);
+                    key = wr.key; idx = wr.idx; pos = wr.pos;
+                    const bool ok = wr.ok != 0;
                     if (ok) { if (lane < m) C.ksel[pos] = (uint8_t)idx; }
                     else if (lane == 0) { Arrays A3 = A; cand_order_index_call(A3, C); }
                     WAVE_SYNC();
