@@ -1908,9 +1908,13 @@ struct WideIdLess { const Ent* e; __device__ bool operator()(uint16_t a, uint16_
 struct WideAuxLess { const Ent* e; __device__ bool operator()(uint16_t a, uint16_t b) const { return e[a].aux < e[b].aux; } };
 struct WideAuxGreater { const Ent* e; __device__ bool operator()(uint16_t a, uint16_t b) const { return e[a].aux > e[b].aux; } };
 
-__device__ __noinline__ void cand_prepare_wide(const Arrays& A, CandT<128>& C, int32_t vbase, double v0, int32_t n0, int32_t t0, bool a0,
+// (the three mode scalars by value, not `const Arrays&`: a reference to the kernel's argument block makes every call store a 200-byte
+// copy of it to the stack -- 24 scratch stores per candidate in the round loop -- for three fields)
+__device__ __noinline__ void cand_prepare_wide(const int32_t o_v, const int32_t o_n, const uint64_t shuffle_seed, CandT<128>& C, int32_t vbase, double v0, int32_t n0, int32_t t0, bool a0,
                                                double v1, int32_t n1, int32_t t1, bool a1, uint8_t* scr, const uint8_t* __restrict__ eqg) {
     ASSUME_LDS(&C); ASSUME_LDS(scr);
+    Arrays A;            // what the callees below read of it (o_v, o_n); lives in registers
+    A.o_v = o_v; A.o_n = o_n; A.shuffle_seed = shuffle_seed;
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     const bool keyed = (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN);
@@ -2441,8 +2445,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                 for (int cc = 0; cc < PASSES / 2; ++cc) {
                     const int32_t i = cc * NWAVE + (tid >> 6);
                     if (i < ncp && !(L.cand[i].flags & CF_BIG)) {   // (wave-uniform)
-                        Arrays A3 = A;
-                        cand_prepare_wide(A3, L.cand[i], G.vbase, lv[2 * cc], ln[2 * cc], lt[2 * cc], la[2 * cc], lv[2 * cc + 1], ln[2 * cc + 1], lt[2 * cc + 1], la[2 * cc + 1], wscr, eqg);
+                        cand_prepare_wide(A.o_v, A.o_n, A.shuffle_seed, L.cand[i], G.vbase, lv[2 * cc], ln[2 * cc], lt[2 * cc], la[2 * cc], lv[2 * cc + 1], ln[2 * cc + 1], lt[2 * cc + 1], la[2 * cc + 1], wscr, eqg);
                     }
                 }
             } else {
