@@ -1764,7 +1764,9 @@ __device__ __noinline__ void cand_order_index_call(const Arrays& A, CT& C) { can
 // the patched candidate.  d's entries live in registers while they are patched and ordered again: by id with a rank count
 // (ids are distinct), by o_n with the half-wave std::sort restatement.  Returns false when d cannot be patched.
 template <int ON, class CT>
-__device__ __noinline__ bool wave_patch(const Arrays& A, CT* cand, int32_t d, int32_t vbase, int32_t* tmp_wave) {
+__device__ __noinline__ bool wave_patch(const int32_t o_v, const uint64_t shuffle_seed, const double* __restrict__ rng, CT* cand, int32_t d, int32_t vbase, int32_t* tmp_wave) {
+    Arrays A;            // (by value, like cand_prepare_wide: what the sampling helpers read of the argument block; lives in registers)
+    A.o_v = o_v; A.o_n = ON; A.shuffle_seed = shuffle_seed; A.rng = rng;
     static_assert(CT::CAP == 32 || CT::CAP == 64, "one entry per lane");
     const int lane = lane_id();
     CT& C = cand[d];
@@ -2782,7 +2784,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     if (i >= *(volatile int32_t*)&s_pmax) lost = true;     // behind a cut already
                     bool okp = false;
-                    if (!lost) { Arrays A3 = A; okp = wave_patch<ON>(A3, L.cand, i, G.vbase, ptmp); }
+                    if (!lost) okp = wave_patch<ON>(A.o_v, A.shuffle_seed, A.rng, L.cand, i, G.vbase, ptmp);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) {
                         if (okp) { atomicOr(&C.flags, CF_PATCHED); s_npatched = 1; }
