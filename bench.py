@@ -108,7 +108,7 @@ def _usable_cores():
 
 def _kernels_sha():
     h = hashlib.sha256()
-    for f in ("rlap_kernels.hip", "rlap_core.h", "rlap_api.hip"):
+    for f in ("rlap_kernels.hip", "rlap_core.h", "rlap_api.hip", "Makefile"):
         h.update(open(os.path.join(ROOT, "rlap_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -32,6 +32,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 
+// This file is compiled twice (Makefile).  rlap_kernels.o has everything but the priority-queue instantiations of the elimination
+// kernel; rlap_kernels_pq.o (-DRLAP_ELIM_PQ_TU -mllvm -disable-machine-licm) has only those: with machine LICM the invariants that get
+// hoisted out of the round loop (LDS base addresses, the reciprocal of n, pointers moved to VGPRs) are spilled in its preheader and
+// reloaded from scratch inside it -- 79 reloads in <degree,asc,32,1024>, 12 without; the o_v = random kernels are better off with it.
+#ifndef RLAP_ELIM_PQ_TU
 // ---------------------------------------------------------------------------
 // K10: MT19937-64 (default seed 5489) -> u = (double)raw / 2^64, clamped below 1
 // (libstdc++ generate_canonical, bits/random.tcc:3348-3380).  One workgroup.
@@ -378,6 +383,7 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const VRec* 
     if (last) oend[b] = i + 1;
 }
 
+#endif  // !RLAP_ELIM_PQ_TU
 // ---------------------------------------------------------------------------
 // K5-K8: elimination.  One 1024-thread workgroup per graph runs rounds of the batch
 // ("frontier") scheme; vertices it cannot take (long columns, multi-edges, keys
@@ -3456,6 +3462,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
 }
 #undef BSYNC
 
+#ifndef RLAP_ELIM_PQ_TU
 // The handle's tables of std::sort's permutation of 17..BC all-equal keys (layout: rlap_kernels.h EQTAB_*), built once.
 template <int BC>
 __global__ __launch_bounds__(64) void k_eq_tables(uint8_t* __restrict__ out) {
@@ -3486,6 +3493,10 @@ void launch_eq_tables(hipStream_t stream, uint8_t* out) {
     hipLaunchKernelGGL(k_eq_tables<128>, dim3(1), dim3(64), 0, stream, out + EQTAB_OFF128);
 }
 
+// the priority-queue instantiations live in the other translation unit (top of this file)
+void launch_eliminate_pq(int o_v, int o_n, unsigned G, bool many, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
+                         int32_t* batch_pos, const int32_t* flags, const double* acc);
+
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
                             int32_t* batch_pos, const int32_t* flags, const double* acc, bool wide) {
     // o_v = random meets long columns all the time (19 % of BA(1M,10) have more than 32 live entries when their
@@ -3510,11 +3521,23 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t 
         else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, flags, acc); \
         return; }
     RLAP_CASE(OV_RANDOM, ON_ASC, 64) RLAP_CASE(OV_RANDOM, ON_DESC, 64) RLAP_CASE(OV_RANDOM, ON_RANDOM, 64)
+#undef RLAP_CASE
+    launch_eliminate_pq(o_v, o_n, G, many, stream, A, gd, S, batch_pos, flags, acc);
+}
+#else   // RLAP_ELIM_PQ_TU
+void launch_eliminate_pq(int o_v, int o_n, unsigned G, bool many, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
+                         int32_t* batch_pos, const int32_t* flags, const double* acc) {
+#define RLAP_CASE(OV, ON, BC) if (o_v == OV && o_n == ON) { \
+        if (many) hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 256>), dim3(G), dim3(256), 0, stream, A, gd, S, batch_pos, flags, acc); \
+        else hipLaunchKernelGGL((k_eliminate_batch_t<OV, ON, BC, 1024>), dim3(G), dim3(1024), 0, stream, A, gd, S, batch_pos, flags, acc); \
+        return; }
     RLAP_CASE(OV_DEGREE, ON_ASC, 32) RLAP_CASE(OV_DEGREE, ON_DESC, 32) RLAP_CASE(OV_DEGREE, ON_RANDOM, 32)
     RLAP_CASE(OV_COARSEN, ON_ASC, 32) RLAP_CASE(OV_COARSEN, ON_DESC, 32) RLAP_CASE(OV_COARSEN, ON_RANDOM, 32)
 #undef RLAP_CASE
 }
+#endif  // RLAP_ELIM_PQ_TU
 
+#ifndef RLAP_ELIM_PQ_TU
 // ---------------------------------------------------------------------------
 // K9: output.  sc_keys/sc_perm: pop order of the surviving vertices;
 // sc_merge (pass A): per vertex gather -> sort -> merge -> order -> staging;
@@ -4521,4 +4544,5 @@ __global__ void k_graph_rows(const int64_t* __restrict__ surv_base, const int64_
     out_ptr[g] = row_off[surv_base[g]];
 }
 
+#endif  // !RLAP_ELIM_PQ_TU
 }  // namespace rlap

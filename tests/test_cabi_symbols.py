@@ -56,8 +56,17 @@ def test_elimination_kernels_keep_their_register_and_lds_budget(tmp_path):
         pytest.skip("ROCm LLVM tools not found")
     fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "dev.co")
     subprocess.check_call([tools[0], "--dump-section", f".hip_fatbin={fat}", _lib.LIB_PATH, str(tmp_path / "unused.so")])
-    subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
-    notes = subprocess.check_output([tools[2], "--notes", co], text=True)
+    # one offload bundle per translation unit (the elimination kernel's source is compiled twice, csrc/Makefile): read them all
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundle in the library"
+    notes = ""
+    for k, st in enumerate(starts):
+        part = str(tmp_path / f"fat{k}.bin")
+        open(part, "wb").write(blob[st: starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", f"--input={part}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+        notes += subprocess.check_output([tools[2], "--notes", co], text=True)
     kernels = {}
     cur = {}
     for line in notes.splitlines():

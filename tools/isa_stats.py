@@ -1,6 +1,7 @@
 """Register / spill statistics of the elimination kernel's instantiations from the ISA (no GPU needed):
     python tools/isa_stats.py [extra hipcc flags ...]
-compiles rlap_amd/csrc/rlap_kernels.hip for gfx950 to assembly (device only, about three minutes) and prints, per instantiation of
+compiles rlap_amd/csrc/rlap_kernels.hip for gfx950 to assembly (device only, about three minutes; once per translation unit of
+csrc/Makefile) and prints, per instantiation of
 k_eliminate_batch_t, the instruction count, SGPRs / VGPRs, scratch size and the number of scratch loads / stores and of
 v_readlane / v_writelane (SGPR spills parked in VGPR lanes).  Why: the kernel sits at both register limits, and DESIGN.md section 5
 (round 3) found that its run time has two states decided by where the allocator puts its reloads -- the committed build has 79
@@ -17,8 +18,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
+    # the two translation units of csrc/Makefile: everything but the priority-queue instantiations, then those (machine LICM off)
+    for tag, extra in (("rlap_kernels.o", []), ("rlap_kernels_pq.o", ["-DRLAP_ELIM_PQ_TU", "-mllvm", "-disable-machine-licm"])):
+        print(f"--- {tag}: hipcc ... {' '.join(extra + sys.argv[1:])}")
+        table(extra + sys.argv[1:])
+
+
+def table(flags):
     out = os.path.join(tempfile.gettempdir(), "rlap_kernels_isa.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *sys.argv[1:],
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *flags,
            "-S", "--cuda-device-only", os.path.join(ROOT, "rlap_amd", "csrc", "rlap_kernels.hip"), "-o", out]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
