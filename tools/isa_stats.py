@@ -4,9 +4,9 @@ compiles rlap_amd/csrc/rlap_kernels.hip for gfx950 to assembly (device only, abo
 csrc/Makefile) and prints, per instantiation of
 k_eliminate_batch_t, the instruction count, SGPRs / VGPRs, scratch size and the number of scratch loads / stores and of
 v_readlane / v_writelane (SGPR spills parked in VGPR lanes).  Why: the kernel sits at both register limits, and DESIGN.md section 5
-(round 3) found that its run time has two states decided by where the allocator puts its reloads -- the committed build has 79
-scratch loads in <degree, asc, 32, 1024> and runs C3 in 283 ms, every build with 130-160 of them runs it in about 300.  A change can be
-screened here before it is measured."""
+(round 3) found that its run time follows where the allocator puts its reloads -- with 79 scratch loads in <degree, asc, 32, 1024>
+C3 ran in 283 ms, every build with 130-160 of them in about 300, the present one (12, machine LICM off for the priority-queue
+kernels) in 278.  A change can be screened here before it is measured."""
 import collections
 import os
 import re
