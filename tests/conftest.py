@@ -19,8 +19,8 @@ def host_mirror():
     import ctypes
     src = os.path.join(ROOT, "tests", "csrc", "host_mirror.cc")
     so = os.path.join(ROOT, "tests", "csrc", "libhost_mirror.so")
-    hdr = os.path.join(ROOT, "rlap_amd", "csrc", "rlap_core.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "rlap_amd", "csrc", h) for h in ("rlap_core.h", "rlap_flow.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-msse4.2", "-mavx", "-fPIC", "-shared", "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.mirror_approx_chol.restype = ctypes.c_int

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../rlap_amd/csrc/rlap_core.h"
+#include "../../rlap_amd/csrc/rlap_flow.h"
 
 using namespace rlap;
 
@@ -520,4 +521,259 @@ int mirror_approx_chol_batch_bc(const int64_t* row, const int64_t* col, const do
 }
 
 void mirror_free(double* p) { std::free(p); }
+}
+
+// ---------------------------------------------------------------------------
+// The dataflow ("flow") form of the elimination for o_v = random (rlap_flow.h), run by `nwaves` virtual waves that a seeded
+// scheduler interleaves at random, one small step at a time: claim -> wait for pend == 0 -> gather / sort / merge / order /
+// publish the count -> look-back for the uniform offset -> sample -> commit (one appended entry per step, in a shuffled order
+// of the positions: concurrent eliminations reach a column out of order, and so do the lanes of one) -> decrements.
+// Every step uses only what the kernel has at that point.  Then the header links, the tag order of the surviving columns and
+// the ordinary output pass.  stats_out: [0] gathers that found equal ids, [1] surviving columns whose appended entries were out
+// of order, [2] max positions in flight, [3] appended entries, [4] chunks beyond the inline directory.
+// ---------------------------------------------------------------------------
+namespace {
+struct FEnt { double val; int32_t nbr, twin, tag; };
+struct FWave {
+    int state = 0;            // 0 claim, 1 wait pend, 2 look-back, 3 commit entries, 4 decrements, 5 done
+    int32_t idx = -1, v = -1;
+    std::vector<FEnt> fin;    // final (o_n) order, merged
+    std::vector<int32_t> dupcnt;   // per merged entry: duplicates folded into it
+    std::vector<int32_t> kill;     // twins of merged duplicates
+    std::vector<int32_t> ksel;
+    std::vector<double> newv;
+    std::vector<int32_t> jorder;
+    int64_t D = 0;
+    size_t jnext = 0;
+};
+}
+
+extern "C" int mirror_flow_chol(const int64_t* row, const int64_t* col, const double* w, int64_t E, int64_t n, int64_t t, int o_n,
+                                const int64_t* perm, uint64_t shuffle_seed, int32_t pool_slots, int32_t nwaves, uint64_t sched_seed,
+                                double** out, int64_t* out_rows, int64_t* stats_out) {
+    Setup S;
+    S.build(row, col, w, E, n, t, OV_RANDOM, o_n, perm, shuffle_seed, pool_slots);
+    const Arrays& A = S.A;
+    int64_t nelim = std::min<int64_t>(t, n - 1);
+    if (nelim < 0) nelim = 0;
+    // ---- flow state ----
+    const int32_t Q = (int32_t)nelim + 1;
+    std::vector<int32_t> cdir((size_t)n * FDIR, FD_EMPTY), atag((size_t)A.slot_cap, -1), qv((size_t)Q, -1), qg((size_t)Q, 0), ctrl(4, 0);
+    std::vector<unsigned long long> lb((size_t)Q, 0ull);
+    FlowArrays F;
+    F.cdir = cdir.data(); F.atag = atag.data(); F.lb = lb.data(); F.qv = qv.data(); F.qg = qg.data(); F.ctrl = ctrl.data(); F.Q = Q;
+    lb[0] = LB_VALID | LB_PREFIX;   // sentinel: prefix 0
+    for (int64_t v = 0; v < n; ++v) { A.vr[v].key = 0; A.vr[v].pqpos = FPOS_NONE; }
+    for (int64_t p = 0; p < nelim; ++p) { int32_t v = (int32_t)S.perm_l[n - 1 - p]; qv[1 + p] = v; A.vr[v].pqpos = (int32_t)(1 + p); }
+    for (int64_t u = 0; u < n; ++u)
+        for (int32_t s = A.colptr[u]; s < A.colptr[u + 1]; ++s) {
+            const int32_t a = A.e[s].nbr;
+            if (A.e[s].val > 0 && A.vr[u].pqpos < A.vr[a].pqpos && A.vr[a].pqpos != FPOS_NONE) A.vr[a].key += 1;
+        }
+    std::mt19937_64 sched(sched_seed);
+    int64_t st_dupgather = 0, st_unsorted = 0, st_inflight_max = 0, st_appended = 0, st_ovf = 0;
+    auto chunk_base = [&](int32_t k, int c) -> int32_t {   // directory look-up, allocating on first use
+        int32_t* word;
+        if (c < FDIR - 1) word = &cdir[(size_t)k * FDIR + c];
+        else {
+            int32_t& ow = cdir[(size_t)k * FDIR + FDIR - 1];
+            if (ow == FD_EMPTY) {
+                int32_t base = pool_take(A.pool_top, FDIR_OVF_SLOTS);
+                if (base < 0 || base > A.slot_cap - FDIR_OVF_SLOTS) return FD_FAIL;
+                int32_t* o = reinterpret_cast<int32_t*>(A.e + base);
+                for (int q = 0; q < FDIR_OVF; ++q) o[q] = FD_EMPTY;
+                ow = base; ++st_ovf;
+            }
+            word = reinterpret_cast<int32_t*>(A.e + ow) + (c - (FDIR - 1));
+        }
+        if (*word == FD_EMPTY) {
+            int32_t need = 1 + chunk_cap(c);
+            int32_t base = pool_take(A.pool_top, need);
+            if (base < 0 || base > A.slot_cap - need) return FD_FAIL;
+            *word = base;
+        }
+        return *word;
+    };
+    auto order_keyed = [&](std::vector<FEnt>& b, int32_t v) {   // o_n order of the merged, id-sorted entries (:661-673)
+        const int32_t m = (int32_t)b.size();
+        std::vector<SRec> rec((size_t)std::max(m, 1));
+        if (o_n == ON_RANDOM) {
+            uint64_t base = keyed_order_base(A.shuffle_seed, v, 0);
+            for (int32_t i = 0; i < m; ++i) { rec[i].key = keyed_order_dkey(base, b[i].nbr); rec[i].idx = i; rec[i].aux = 0; }
+            std_sort_emul<false>(rec.data(), m);
+        } else {
+            for (int32_t i = 0; i < m; ++i) { rec[i].key = b[i].val; rec[i].idx = i; rec[i].aux = 0; }
+            if (o_n == ON_ASC) std_sort_emul<false>(rec.data(), m); else std_sort_emul<true>(rec.data(), m);
+        }
+        std::vector<int32_t> p((size_t)m);
+        for (int32_t i = 0; i < m; ++i) p[i] = rec[i].idx;
+        return p;
+    };
+    std::vector<FWave> W((size_t)std::max(nwaves, 1));
+    int64_t ndone = 0;
+    auto step = [&](FWave& X) -> int {
+        switch (X.state) {
+        case 0: {
+            int32_t idx = ctrl[0]++;
+            while (idx < Q && qv[idx] < 0) idx = ctrl[0]++;   // sentinels
+            if (idx >= Q) { X.state = 5; ++ndone; return 0; }
+            X.idx = idx; X.v = qv[idx]; X.state = 1;
+            return 0;
+        }
+        case 1: {
+            const int32_t v = X.v;
+            if (A.vr[v].key != 0) return 0;
+            // ---- gather in PHYSICAL order: appended index descending, then the CSR segment descending ----
+            std::vector<FEnt> a;
+            const int32_t acnt = A.vr[v].app_cnt;
+            for (int32_t i = acnt - 1; i >= 0; --i) {
+                const int c = chunk_of(i);
+                const int32_t base = c < FDIR - 1 ? cdir[(size_t)v * FDIR + c] : reinterpret_cast<int32_t*>(A.e + cdir[(size_t)v * FDIR + FDIR - 1])[c - (FDIR - 1)];
+                if (base < 0) return ST_INTERNAL;
+                const int32_t s = base + 1 + (i - chunk_start(c));
+                if (A.e[s].val > 0) a.push_back({A.e[s].val, A.e[s].nbr, A.e[s].twin, atag[s]});
+            }
+            const size_t napp = a.size();
+            for (int32_t s = A.colptr[v + 1] - 1; s >= A.colptr[v]; --s) if (A.e[s].val > 0) a.push_back({A.e[s].val, A.e[s].nbr, A.e[s].twin, -1});
+            for (const FEnt& e : a) if (A.vr[e.nbr].pqpos < X.idx) return ST_INTERNAL;   // an earlier vertex still in the column: the counters are wrong
+            auto sort_by_id = [&](std::vector<FEnt>& x) {
+                std::vector<SRec> rec(std::max<size_t>(x.size(), 1));
+                for (size_t i = 0; i < x.size(); ++i) { rec[i].key = (double)x[i].nbr; rec[i].idx = (int32_t)i; rec[i].aux = 0; }
+                std_sort_emul<false>(rec.data(), (int)x.size());
+                std::vector<FEnt> y(x.size());
+                for (size_t i = 0; i < x.size(); ++i) y[i] = x[rec[i].idx];
+                return y;
+            };
+            std::vector<FEnt> sorted = sort_by_id(a);
+            bool dup = false;
+            for (size_t i = 1; i < sorted.size(); ++i) if (sorted[i].nbr == sorted[i - 1].nbr) dup = true;
+            if (dup) {   // equal ids: the list order matters -- appended entries newest first (descending tag), and sort again
+                ++st_dupgather;
+                std::sort(a.begin(), a.begin() + (long)napp, [](const FEnt& p, const FEnt& q) { return p.tag > q.tag; });
+                sorted = sort_by_id(a);
+            }
+            // ---- merge (:646-659): the first of a run survives with the sum, the others' twins die ----
+            std::vector<FEnt> b;
+            X.dupcnt.clear(); X.kill.clear();
+            for (size_t i = 0; i < sorted.size(); ++i) {
+                if (b.empty() || sorted[i].nbr != b.back().nbr) { b.push_back(sorted[i]); X.dupcnt.push_back(0); }
+                else { b.back().val += sorted[i].val; X.kill.push_back(sorted[i].twin); X.dupcnt.back() += 1; }
+            }
+            std::vector<int32_t> p = order_keyed(b, v);
+            const int32_t m = (int32_t)b.size();
+            X.fin.resize((size_t)m);
+            std::vector<int32_t> dc((size_t)m);
+            for (int32_t j = 0; j < m; ++j) { X.fin[j] = b[p[j]]; dc[j] = X.dupcnt[p[j]]; }
+            X.dupcnt = dc;
+            const int64_t c = m > 1 ? m - 1 : 0;
+            lb[X.idx] = LB_VALID | (unsigned long long)c;   // own count
+            X.state = 2;
+            return 0;
+        }
+        case 2: {
+            // decoupled look-back: own count is published; walk back to the nearest inclusive prefix
+            unsigned long long sum = 0;
+            for (int32_t q = X.idx - 1;; --q) {
+                const unsigned long long wv = lb[q];
+                if (!(wv & LB_VALID)) return 0;   // not there yet
+                sum += wv & LB_MASK;
+                if (wv & LB_PREFIX) break;
+            }
+            const int32_t m = (int32_t)X.fin.size();
+            const int64_t c = m > 1 ? m - 1 : 0;
+            X.D = (int64_t)sum;
+            if (X.D + c > A.rng_len) return ST_RNG_OVERFLOW;
+            lb[X.idx] = LB_VALID | LB_PREFIX | (unsigned long long)(X.D + c);
+            // ---- sample (:728-779) ----
+            std::vector<double> cum((size_t)std::max(m, 1));
+            double csum = 0;
+            for (int32_t j = 0; j < m; ++j) { csum += X.fin[j].val; cum[j] = csum; }
+            X.ksel.assign((size_t)std::max(m, 1), 0); X.newv.assign((size_t)std::max(m, 1), 0.0);
+            double wdeg = csum, colScale = 1;
+            for (int32_t j = 0; j < m - 1; ++j) {
+                double ww = X.fin[j].val * colScale;
+                double f = ww / wdeg;
+                double u = A.rng[X.D + j];
+                double r = u * (csum - cum[j]) + cum[j];
+                X.ksel[j] = upper_index(cum.data(), m, r);
+                double omf = 1 - f;
+                X.newv[j] = f * omf * wdeg;
+                colScale = colScale * omf;
+                wdeg = wdeg * omf * omf;
+            }
+            X.jorder.resize((size_t)std::max(m - 1, 0));
+            for (int32_t j = 0; j < m - 1; ++j) X.jorder[j] = j;
+            std::shuffle(X.jorder.begin(), X.jorder.end(), sched);
+            X.jnext = 0;
+            X.state = 3;
+            return 0;
+        }
+        case 3: {
+            const int32_t m = (int32_t)X.fin.size();
+            if (X.jnext < X.jorder.size()) {
+                const int32_t j = X.jorder[X.jnext++];
+                const int32_t k = X.fin[X.ksel[j]].nbr, a = X.fin[j].nbr, s_r = X.fin[j].twin;
+                const double nw = X.newv[j];
+                const int32_t ai = A.vr[k].app_cnt++;   // (atomic on the device)
+                const int c = chunk_of(ai);
+                const int32_t base = chunk_base(k, c);
+                if (base < 0) return ST_POOL_OVERFLOW;
+                const int32_t s_n = base + 1 + (ai - chunk_start(c));
+                ++st_appended;
+                A.e[s_n].nbr = a; A.e[s_n].val = nw; A.e[s_n].twin = s_r;
+                atag[s_n] = (int32_t)(X.D + j);
+                A.e[s_r].nbr = k; A.e[s_r].val = nw; A.e[s_r].twin = s_n;
+                if (nw > 0) {   // a live pair: it waits at whichever end comes later for the one that comes earlier
+                    const int32_t pa = A.vr[a].pqpos, pk = A.vr[k].pqpos;
+                    if (pk < pa && pa != FPOS_NONE) A.vr[a].key += 1;
+                    if (pa < pk && pk != FPOS_NONE) A.vr[k].key += 1;
+                }
+                return 0;
+            }
+            if (m >= 1) A.e[X.fin[m - 1].twin].val = 0;          // :791-792
+            for (int32_t tw : X.kill) A.e[tw].val = 0;          // :655
+            X.state = 4;
+            return 0;
+        }
+        case 4: {
+            for (size_t j = 0; j < X.fin.size(); ++j) {
+                const int32_t a = X.fin[j].nbr;
+                if (A.vr[a].pqpos != FPOS_NONE) { A.vr[a].key -= 1 + X.dupcnt[j]; if (A.vr[a].key < 0) return ST_INTERNAL; }
+            }
+            X.state = 0;
+            return 0;
+        }
+        default: return 0;
+        }
+    };
+    int64_t idle = 0;
+    while (ndone < (int64_t)W.size()) {
+        FWave& X = W[(size_t)(sched() % W.size())];
+        const int before = X.state; const size_t jb = X.jnext;
+        int rc = step(X);
+        if (rc) return rc;
+        if (X.state == before && X.jnext == jb) { if (++idle > 50000000) return ST_INTERNAL; } else idle = 0;
+        int64_t infl = 0; for (const FWave& Y : W) infl += (Y.state >= 1 && Y.state <= 4); if (infl > st_inflight_max) st_inflight_max = infl;
+    }
+    for (int64_t v = 0; v < n; ++v) if (A.vr[v].pqpos != FPOS_NONE && A.vr[v].key != 0) return ST_INTERNAL;
+    S.G.n_draws = (int64_t)(lb[(size_t)Q - 1] & LB_MASK);
+    // ---- afterwards: header links, tag order of the surviving columns ----
+    for (int64_t v = 0; v < n; ++v) flow_finish_vertex(A, F, (int32_t)v);
+    for (int64_t q = nelim; q < n; ++q) {
+        const int32_t v = (int32_t)S.perm_l[n - 1 - q];
+        const int32_t acnt = A.vr[v].app_cnt;
+        std::vector<int32_t> slots;
+        for (int32_t i = 0; i < acnt; ++i) { const int c = chunk_of(i); const int32_t base = c < FDIR - 1 ? cdir[(size_t)v * FDIR + c] : reinterpret_cast<int32_t*>(A.e + cdir[(size_t)v * FDIR + FDIR - 1])[c - (FDIR - 1)]; slots.push_back(base + 1 + (i - chunk_start(c))); }
+        bool sorted_already = true;
+        for (int32_t i = 1; i < acnt; ++i) if (atag[slots[i]] < atag[slots[i - 1]]) sorted_already = false;
+        if (sorted_already) continue;
+        ++st_unsorted;
+        std::vector<std::pair<int32_t, Slot>> items;
+        for (int32_t i = 0; i < acnt; ++i) items.push_back({atag[slots[i]], A.e[slots[i]]});
+        std::sort(items.begin(), items.end(), [](const std::pair<int32_t, Slot>& p, const std::pair<int32_t, Slot>& q) { return p.first < q.first; });
+        for (int32_t i = 0; i < acnt; ++i) { A.e[slots[i]] = items[i].second; atag[slots[i]] = items[i].first; }
+    }
+    if (stats_out) { stats_out[0] = st_dupgather; stats_out[1] = st_unsorted; stats_out[2] = st_inflight_max; stats_out[3] = st_appended; stats_out[4] = st_ovf; }
+    for (int64_t v = 0; v < n; ++v) { A.vr[v].key = 0; A.vr[v].pqpos = -1; }
+    return S.finish(nelim, nelim, nullptr, out, out_rows);
 }
