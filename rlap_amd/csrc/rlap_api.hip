@@ -88,6 +88,8 @@ struct rlap_handle_s {
     double log_factor = 2.0;
     int64_t rng_min = 0;          // lower bound of the uniform table (grown after an overflow)
     int64_t scr_budget = 1 << 18; // output pass: entries of global scratch for columns beyond 8192 slots
+    double flow_scr_factor = 1.0; // dataflow elimination: working storage of the long columns (grown after ST_FLOW_SCRATCH)
+    bool flow_off_once = false;   // the next attempt uses the round kernel (set after ST_FLOW_REORDER)
     // test hooks (rlap_debug_set_limits): tiny first sizes so that the retry path runs
     double dbg_pool = -1.0, dbg_log = -1.0; int64_t dbg_rng = -1, dbg_scr = -1;
     int64_t total_retries = 0;
@@ -154,7 +156,7 @@ int excl_scan(rlap_handle h, const SortTmp& T, In* in, Out* out, int64_t n) {
 inline unsigned bits_for(uint64_t maxval) { unsigned b = 1; while (b < 64 && (maxval >> b) != 0) ++b; return b; }
 
 // largest temporary any rocPRIM call of a call with these sizes asks for (the very calls run_once makes, asked with null storage)
-int sort_tmp_bytes(int64_t Eeff, int64_t N, int64_t G, int64_t S, size_t* out) {
+int sort_tmp_bytes(int64_t Eeff, int64_t N, int64_t G, int64_t S, bool flow, size_t* out) {
     size_t mx = 256, b = 0;
     hipStream_t s0 = nullptr;
     const unsigned kbits = bits_for((uint64_t)(N > 1 ? N - 1 : 1)), gbits = bits_for((uint64_t)(G > 0 ? G - 1 : 0));
@@ -168,8 +170,19 @@ int sort_tmp_bytes(int64_t Eeff, int64_t N, int64_t G, int64_t S, size_t* out) {
     b = 0; HIPCHK(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, Nn, 0u, 32u + gbits, s0)); mx = std::max(mx, b);
     b = 0; HIPCHK(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, Nn, 0u, 64u, s0)); mx = std::max(mx, b);
     b = 0; HIPCHK(rocprim::exclusive_scan(nullptr, b, (int32_t*)nullptr, (int64_t*)nullptr, (int64_t)0, (size_t)(S + 1), rocprim::plus<int64_t>(), s0)); mx = std::max(mx, b);
+    if (flow && Eeff > 0) {   // tag order of the surviving columns (rlap_flow.hip): one (column, tag) sort over at most Eeff appended entries
+        b = 0; HIPCHK(rocprim::radix_sort_pairs(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)Eeff, 0u, 64u, s0)); mx = std::max(mx, b);
+        b = 0; HIPCHK(rocprim::exclusive_scan(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(S + 1), rocprim::plus<int32_t>(), s0)); mx = std::max(mx, b);
+    }
     *out = mx;
     return RLAP_OK;
+}
+
+// o_v = random runs the dataflow kernel (rlap_flow.hip) unless RLAP_FLOW=0 asks for the round kernel
+inline bool flow_wanted(const rlap_handle h, int o_v) {
+    if (o_v != OV_RANDOM || h->flow_off_once) return false;
+    const char* e = std::getenv("RLAP_FLOW");
+    return e ? (e[0] != '0') : false;
 }
 
 constexpr int64_t SORT_SKIP_MIN = 1 << 21;   // directed entries from which the order of the input is looked at before sorting it
@@ -212,10 +225,13 @@ struct Sizes {
     int64_t G, N, Eeff, slot_cap, bucket_total, log_total, scr_total, S, scr_budget;
     size_t sort_tmp, res_bytes;
     bool want_genperm;
+    bool flow;                    // dataflow elimination (o_v = random): its arrays are part of the arena
+    int64_t flow_Q, flow_scr;     // look-back words (positions + one sentinel per graph); entries of long-column working storage
 };
 struct WBuf { void* p = nullptr; template <class T> T* as() const { return reinterpret_cast<T*>(p); } };
 struct WS {
-    WBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, colptr, slot_col, permchk, genperm, ent, vrec, ocur, oend, origpos, orig_order, gd_d, pool_top, bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, skey0, skey1, sval0, sval1, scr_rec, scr_i32, scr_f64, surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, sc_rec, sc_i32, sc_f64, biglist, hugelists, results;
+    WBuf node_ptr_d, vgraph, scal, keys0, keys1, idx0, idx1, head, pos, sorttmp, colptr, slot_col, permchk, genperm, ent, vrec, ocur, oend, origpos, orig_order, gd_d, pool_top, bs_cnt, bs_alloc, bs_dir, bs_v, bs_id, bs_pool_top, batch_pos, skey0, skey1, sval0, sval1, scr_rec, scr_i32, scr_f64, surv_base_d, ext, tmp_off, tmp_nbr, tmp_val, cnt, row_off, sc_rec, sc_i32, sc_f64, biglist, hugelists, results,
+         f_cdir, f_atag, f_lb, f_qv, f_qg, f_ctrl, f_scr, f_rocnt, f_rooff;
 };
 inline size_t host_block_bytes(int64_t G) { return 16 * (size_t)(G + 1) + sizeof(GraphDesc) * (size_t)G; }
 // the arena's layout: run once with a null base to learn the size, once more to place the buffers
@@ -255,11 +271,19 @@ size_t carve(Carver& C, const Sizes& z, WS& W) {
     W.sc_rec.p = C.take<SRec>(z.scr_budget); W.sc_i32.p = C.take<int32_t>(7 * z.scr_budget); W.sc_f64.p = C.take<double>(2 * z.scr_budget);
     W.biglist.p = C.take<int32_t>(8 * (S + 1));
     W.hugelists.p = C.take<uint16_t>((int64_t)NHUGE * 2 * (HUGECAP + 2));
+    if (z.flow) {
+        W.f_ctrl.p = C.take<int32_t>(64);
+        W.f_cdir.p = C.take<int32_t>(N * FDIR);
+        W.f_atag.p = C.take<int32_t>(z.slot_cap);
+        W.f_lb.p = C.take<unsigned long long>(z.flow_Q); W.f_qv.p = C.take<int32_t>(z.flow_Q); W.f_qg.p = C.take<int32_t>(z.flow_Q);
+        W.f_scr.p = C.take<char>(z.flow_scr * FLOW_SCR_BYTES);
+        W.f_rocnt.p = C.take<int32_t>(S + 1); W.f_rooff.p = C.take<int32_t>(S + 1);
+    }
     return (C.off + 255) & ~(size_t)255;
 }
 
 // sizes of a call on (E directed input entries, N vertices, G graphs, S surviving vertices) under the handle's growth factors
-int call_sizes(const rlap_handle h, int64_t Eeff, int64_t N, int64_t G, int64_t bucket_total, int64_t S, bool want_genperm, Sizes* z) {
+int call_sizes(const rlap_handle h, int64_t Eeff, int64_t N, int64_t G, int64_t bucket_total, int64_t S, bool want_genperm, bool flow, int64_t nelim_total, Sizes* z) {
     const double pool_factor = h->dbg_pool >= 0 ? h->dbg_pool : h->pool_factor;
     const double log_factor = h->dbg_log >= 0 ? h->dbg_log : h->log_factor;
     const int64_t nnz_ub = Eeff;
@@ -273,7 +297,11 @@ int call_sizes(const rlap_handle h, int64_t Eeff, int64_t N, int64_t G, int64_t 
     z->scr_budget = h->dbg_scr >= 0 ? h->dbg_scr : h->scr_budget;
     z->res_bytes = sizeof(CallResults) + 8 * (size_t)(G + 1);
     z->want_genperm = want_genperm;
-    return sort_tmp_bytes(Eeff, N, G, S, &z->sort_tmp);
+    z->flow = flow;
+    z->flow_Q = nelim_total + G;
+    z->flow_scr = flow ? (int64_t)(h->flow_scr_factor * (double)std::max<int64_t>(Eeff / 16, 1 << 17)) : 0;
+    if (z->flow_scr >= ((int64_t)1 << 31) - 64) z->flow_scr = ((int64_t)1 << 31) - 64;
+    return sort_tmp_bytes(Eeff, N, G, S, flow, &z->sort_tmp);
 }
 
 // uniforms a call may draw: a graph rarely draws more than its own directed entry count; an overflow doubles the table
@@ -326,13 +354,15 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         D.bucket_base = (int32_t)bucket_total; bucket_total += 2 * n + 1;
         int64_t ne = std::max<int64_t>(0, std::min<int64_t>(c.h_t[g], n - 1));
         D.n_elim = (int32_t)ne;
+        D.flow_base = (int32_t)(nelim_total + g);
         nelim_total += ne;
         surv_base[g + 1] = surv_base[g] + (n - ne);
     }
     const int64_t S = surv_base[G];
     st.n_eliminated = nelim_total;
     Sizes z;
-    { int rc = call_sizes(h, Eeff, N, G, bucket_total, S, c.o_v == OV_RANDOM && !c.d_perm, &z); if (rc) return rc; }
+    const bool flow = flow_wanted(h, c.o_v);
+    { int rc = call_sizes(h, Eeff, N, G, bucket_total, S, c.o_v == OV_RANDOM && !c.d_perm, flow, nelim_total, &z); if (rc) return rc; }
     const int64_t slot_cap = z.slot_cap, log_total = z.log_total, scr_total = z.scr_total, scr_budget = z.scr_budget;
     const size_t res_bytes = z.res_bytes;
 
@@ -524,6 +554,24 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     // sizes: no read-back).  Measured (ms per call, 64 -> 128 slots): BA(1M,10) 2950 -> 2180, BA(169343,7) 260 -> 248, BA(4096,8)
     // 10.2 -> 9.2; BA(20000,5) 23.0 -> 23.4 and sparser graphs lose (their rounds fill 64 candidates and get only 32)
     const bool wide = c.o_v == OV_RANDOM && nnz_ub >= 12 * N && N >= 512;
+    FlowArrays FA;
+    std::memset(&FA, 0, sizeof(FA));
+    if (flow) {
+        // dataflow elimination (rlap_flow.hip): every position of the order is one wave's, on any compute unit
+        FA.cdir = W.f_cdir.as<int32_t>(); FA.atag = W.f_atag.as<int32_t>(); FA.lb = W.f_lb.as<unsigned long long>();
+        FA.qv = W.f_qv.as<int32_t>(); FA.qg = W.f_qg.as<int32_t>(); FA.ctrl = W.f_ctrl.as<int32_t>(); FA.Q = (int32_t)z.flow_Q;
+        FlowParams FP;
+        FP.vgraph = W.vgraph.as<int32_t>(); FP.gd = W.gd_d.as<GraphDesc>(); FP.in_flags = flags; FP.in_acc = acc;
+        FP.scr = W.f_scr.as<char>(); FP.scr_entries = (int32_t)z.flow_scr;
+        FP.spin_limit = 1 << 24; FP.jitter = h->jitter; FP.poison = h->poison;
+        if (const char* e = std::getenv("RLAP_FLOW_SPIN")) FP.spin_limit = std::atoi(e);
+        HIPCHK(hipMemsetAsync(W.f_ctrl.p, 0, 64 * 4, s));
+        launch_flow_setup(s, A, FA, FP, W.slot_col.as<int32_t>(), nnz_p, (int32_t)N, Eeff);
+        unsigned grid = 4u * (unsigned)h->n_cu;
+        if (const char* e = std::getenv("RLAP_FLOW_WAVES")) grid = (unsigned)std::max(1, std::atoi(e));
+        launch_flow_eliminate(c.o_n, grid, s, A, FA, FP);
+        launch_flow_finish(s, A, FA, W.gd_d.as<GraphDesc>(), (int32_t)N, (int32_t)G);
+    } else
     launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, h->n_cu, s, A, W.gd_d.as<GraphDesc>(), ES, W.batch_pos.as<int32_t>(), flags, acc, wide);
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev[2], s));
@@ -534,6 +582,18 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         hipLaunchKernelGGL(k_sc_perm_order, dim3(nblk(N, 256)), dim3(256), 0, s, d_perm, W.vgraph.as<int32_t>(), W.gd_d.as<GraphDesc>(),
                            W.surv_base_d.as<int64_t>(), (int32_t)N, W.sval1.as<uint32_t>());
         order = W.sval1.as<uint32_t>();
+        if (flow && S > 0 && Eeff > 0) {
+            // tag order of the surviving columns: concurrent eliminations pushed into them out of order (rlap_flow.h)
+            const int32_t ro_cap = (int32_t)Eeff;
+            launch_flow_ro_count(s, A, FA, order, (int32_t)S, W.f_rocnt.as<int32_t>());
+            { int rc = excl_scan(h, ST, W.f_rocnt.as<int32_t>(), W.f_rooff.as<int32_t>(), S + 1); if (rc) return rc; }
+            uint32_t* home = reinterpret_cast<uint32_t*>(W.head.p);
+            launch_flow_ro_emit(s, A, FA, order, (int32_t)S, W.f_rooff.as<int32_t>(), W.keys0.as<uint64_t>(), W.idx0.as<uint32_t>(), home, ro_cap, &W.gd_d.as<GraphDesc>()[0].status);
+            const unsigned kb = bits_for((uint64_t)std::max<int64_t>(S - 1, 1)) + 32u;
+            { int rc = sort_pairs(h, ST, W.keys0.as<uint64_t>(), W.keys1.as<uint64_t>(), W.idx0.as<uint32_t>(), W.idx1.as<uint32_t>(), Eeff, 0, std::min(64u, kb)); if (rc) return rc; }
+            launch_flow_ro_permute(s, A, FA, W.f_rooff.as<int32_t>(), (int32_t)S, W.idx1.as<uint32_t>(), W.keys1.as<uint64_t>(), home, ro_cap, reinterpret_cast<Slot*>(W.tmp_val.p));
+            HIPCHK(hipGetLastError());
+        }
     } else {
         hipLaunchKernelGGL(k_sc_keys, dim3(nblk(N, 256)), dim3(256), 0, s, W.vrec.as<VRec>(), W.origpos.as<int32_t>(),
                            W.vgraph.as<int32_t>(), W.gd_d.as<GraphDesc>(), (int32_t)N, W.skey0.as<uint64_t>(), W.sval0.as<uint32_t>());
@@ -622,6 +682,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         if (R.status == ST_POOL_OVERFLOW) *retry_kind = 1;
         else if (R.status == ST_LOG_OVERFLOW) *retry_kind = 2;
         else if (R.status == ST_RNG_OVERFLOW) *retry_kind = 3;
+        else if (R.status == ST_FLOW_SCRATCH) *retry_kind = 6;
+        else if (R.status == ST_FLOW_REORDER) *retry_kind = 7;
         return R.status;
     }
     if (R.flags[FLAG_SCR]) { *retry_kind = 4; *retry_need = R.scr_need; return RLAP_E_INTERNAL; }
@@ -653,8 +715,10 @@ int run_call(rlap_handle h, const Call& c) {
         else if (kind == 3) { if (h->dbg_rng >= 0) h->dbg_rng = -1; else h->rng_min = std::max<int64_t>(2 * h->rng_len, 1 << 16); }
         else if (kind == 4) { if (h->dbg_scr >= 0) h->dbg_scr = -1; h->scr_budget = std::max<int64_t>(h->scr_budget, need + 8); }
         else if (kind == 5) h->force_sort = true;
+        else if (kind == 6) h->flow_scr_factor *= 4;
+        else if (kind == 7) h->flow_off_once = true;
     }
-    h->force_sort = false;
+    h->force_sort = false; h->flow_off_once = false;
     h->total_retries += retries;
     if (c.st) c.st->n_retries = retries;
     return rc;
@@ -711,7 +775,7 @@ static int ws_query(const rlap_handle h, int64_t E, int64_t n_total, int64_t G, 
     const rlap_handle hh = h ? h : &defaults;
     Sizes z;
     // bounds that hold for every split of n_total over G graphs and every num_remove: 2n+1 buckets per graph, S <= n_total
-    int rc = call_sizes(hh, Eeff, n_total, G, 2 * n_total + G, n_total, true, &z);
+    int rc = call_sizes(hh, Eeff, n_total, G, 2 * n_total + G, n_total, true, flow_wanted(hh, OV_RANDOM), n_total, &z);
     if (rc) return rc;
     WS W; Carver dry{nullptr, 0};
     *ws_bytes = carve(dry, z, W);

@@ -36,6 +36,8 @@ enum {
     ST_HIP_ERROR = 8,
     ST_TOO_LARGE = 9,
     ST_INTERNAL = 10,
+    ST_FLOW_SCRATCH = 12,   // dataflow elimination: working storage of the long columns exhausted (the call repeats with more)
+    ST_FLOW_REORDER = 13,   // ... more out-of-order appended entries than the reorder buffers hold (the call repeats with the round kernel)
 };
 
 // ---------------------------------------------------------------------------
@@ -307,6 +309,8 @@ struct GraphDesc {      // one per graph of a batch
     int32_t status;
     int64_t n_draws;
     int64_t out_rows;   // rows this graph emits (filled by the output pass)
+    int32_t flow_base;  // dataflow elimination (rlap_flow.h): look-back index of this graph's sentinel; its positions follow
+    int32_t pad2;
 };
 
 struct ColBuf {         // working storage for one column (LDS or global scratch)

@@ -1,0 +1,673 @@
+// rlap_flow.hip -- the multi-CU ("dataflow") exact elimination for o_v = random on gfx950 (protocol and proof sketch: rlap_flow.h;
+// the same steps run by randomly interleaved virtual waves on the CPU: tests/csrc/host_mirror.cc::mirror_flow_chol).
+//
+// Replaces the loop of RandomPreconditioner::getSchurComplement, /root/reference/rlap/csrc/preconditioner.cc:713-787, for one graph
+// or a batch: every position of the (known) order is claimed by ONE wave -- a 64-thread workgroup, four to a compute unit, on
+// every XCD -- which waits until the vertex's column is final (pend == 0), gathers it, sorts / merges / orders it with the exact
+// std::sort restatements (rlap_wave_sort.h), publishes its uniform count for the look-back, samples and commits.
+//
+// Memory between workgroups (MI355X: the L1 of a CU is never refreshed by other CUs' stores, the L2s of the eight XCDs are
+// not coherent with each other): every word that one workgroup writes and another reads in this launch -- entries, tags,
+// directory words, counters, look-back words -- is written with an agent-scope (sc1, write-through) store or atomic and read
+// with an agent-scope (sc1) load or atomic; a wave waits for its stores (s_waitcnt vmcnt(0)) before the atomic decrements that
+// release its neighbours.  No fences, no plain loads of shared words.  What the launch only reads (colptr, order, positions,
+// uniforms) is loaded normally.
+// Compiled with -ffp-contract=off like the rest (the reference is built without FMA, setup.py:26-37).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstdlib>
+#include <type_traits>
+#include <cstddef>
+#include <algorithm>
+
+#include "rlap_core.h"
+#include "rlap_flow.h"
+#include "rlap_kernels.h"
+#include "rlap_wave_sort.h"
+
+namespace rlap {
+
+// ---------------------------------------------------------------------------
+// agent-scope accesses
+// ---------------------------------------------------------------------------
+#define RLX __ATOMIC_RELAXED
+#define AGT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ int32_t ag_ld(const int32_t* p) { return __hip_atomic_load(p, RLX, AGT); }
+__device__ __forceinline__ void ag_st(int32_t* p, int32_t v) { __hip_atomic_store(p, v, RLX, AGT); }
+__device__ __forceinline__ unsigned long long ag_ld64(const unsigned long long* p) { return __hip_atomic_load(p, RLX, AGT); }
+__device__ __forceinline__ void ag_st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, RLX, AGT); }
+__device__ __forceinline__ int32_t ag_add(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, RLX, AGT); }
+// a 16-byte entry as two 8-byte words (no reader while a writer is at it: rlap_flow.h)
+__device__ __forceinline__ Slot ag_ld_slot(const Slot* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long w0 = ag_ld64(q), w1 = ag_ld64(q + 1);
+    Slot s;
+    s.val = __longlong_as_double((long long)w0);
+    s.nbr = (int32_t)(uint32_t)(w1 & 0xFFFFFFFFull);
+    s.twin = (int32_t)(uint32_t)(w1 >> 32);
+    return s;
+}
+__device__ __forceinline__ void ag_st_slot(Slot* p, double val, int32_t nbr, int32_t twin) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    ag_st64(q, (unsigned long long)__double_as_longlong(val));
+    ag_st64(q + 1, (unsigned long long)(uint32_t)nbr | ((unsigned long long)(uint32_t)twin << 32));
+}
+__device__ __forceinline__ void ag_st_slot_val(Slot* p, double val) { ag_st64(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(val)); }
+#define DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+
+// ---------------------------------------------------------------------------
+// working storage of one column: LDS arrays (short columns) or pointers into the bump-allocated scratch (long ones)
+// ---------------------------------------------------------------------------
+template <int EC>
+struct FlowLds {
+    static constexpr bool SMALL = true;
+    static constexpr int CAP = EC;
+    SRec rec[EC];                 // sort records; after the ordering: cum[EC] | newv[EC]
+    double a_val[EC], b_val[EC];
+    alignas(16) double skey[EC + 8];
+    int32_t a_nbr[EC], a_twin[EC], a_tag[EC];      // a_tag: tags while the list order is restored, then the twins of merged duplicates
+    int32_t b_nbr[EC], b_twin[EC], b_dup[EC], b_pos[EC];
+    int32_t f_dup[EC], f_pos[EC];                  // f_dup doubles as the register sort's scratch and the level sort's second table
+    int32_t ksel[EC];                              // doubles as the level sort's first table
+    uint16_t ulist[EC + 2], dlist[EC + 2];
+    uint32_t segmark[(EC + 31) / 32 + 1];
+    int32_t stk[3 * 48];
+    __device__ double* cum() { return reinterpret_cast<double*>(rec); }
+    __device__ double* newv() { return reinterpret_cast<double*>(rec) + EC; }
+};
+struct FlowGlob {
+    static constexpr bool SMALL = false;
+    SRec* rec;
+    double *a_val, *b_val, *skey, *cum_, *newv_;
+    int32_t *a_nbr, *a_twin, *a_tag, *b_nbr, *b_twin, *b_dup, *b_pos, *f_dup, *f_pos, *ksel;
+    uint16_t *ulist, *dlist;
+    uint32_t* segmark;
+    int32_t* stk;
+    __device__ double* cum() { return cum_; }
+    __device__ double* newv() { return newv_; }
+};
+// long columns: sort records and stop lists through generic pointers into the wave's LDS (0: everything in global scratch)
+constexpr bool FLOW_BIG_IN_LDS = false;
+static_assert(FLOW_SCR_BYTES >= 16 + 5 * 8 + 10 * 4 + 2 * 2 + 1 && FLOW_SCR_BYTES % 8 == 0, "records, five doubles, ten ints, two 16-bit lists and the segment marks per entry");
+
+// std::sort order of the staged keys B.skey[0..cnt) into B.rec[] = {key, source index} (rlap_wave_sort.h)
+template <bool GREATER, class BUF>
+__device__ __forceinline__ void flow_sort(BUF& B, int cnt, int lane) {
+    typedef typename std::conditional<GREATER, SRecGreaterKey, SRecLessKey>::type Cmp;
+    if constexpr (BUF::SMALL) {
+        if (cnt <= 64) {
+            double key = lane < cnt ? B.skey[lane] : 0.0;
+            int idx = lane, pos = lane;
+            const bool ok = wave_sort64<GREATER>(key, idx, cnt, lane, B.f_dup, &pos);
+            if (ok) {
+                if (lane < cnt) { B.rec[pos].key = key; B.rec[pos].idx = idx; }
+                WAVE_SYNC();
+                return;
+            }
+        }
+        WAVE_SYNC();
+        for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; }
+        WAVE_SYNC();
+        bool ok;
+        constexpr int REGMAX = (BUF::CAP + 63) / 64;
+        if (cnt <= 128) ok = wave_lvl_sort<SRec, Cmp, 2>(B.rec, cnt, Cmp(), B.ulist, B.dlist, reinterpret_cast<uint32_t*>(B.ksel), reinterpret_cast<uint16_t*>(B.f_dup), lane);
+        else if (cnt <= 256) ok = wave_lvl_sort<SRec, Cmp, 4>(B.rec, cnt, Cmp(), B.ulist, B.dlist, reinterpret_cast<uint32_t*>(B.ksel), reinterpret_cast<uint16_t*>(B.f_dup), lane);
+        else ok = wave_lvl_sort<SRec, Cmp, REGMAX>(B.rec, cnt, Cmp(), B.ulist, B.dlist, reinterpret_cast<uint32_t*>(B.ksel), reinterpret_cast<uint16_t*>(B.f_dup), lane);
+        if (!ok) {   // depth limit: std::sort heap-sorts there; start over with the form that follows it
+            WAVE_SYNC();
+            for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; }
+            WAVE_SYNC();
+            const WaveSortPtrs WP = {B.ulist, B.dlist, B.segmark, B.stk};
+            wave_std_sort<SRec, Cmp, REGMAX>(B.rec, cnt, Cmp(), WP, lane);
+        }
+        WAVE_SYNC();
+    } else {
+        for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; B.rec[i].aux = 0; }
+        WAVE_SYNC();
+        if (cnt <= 65000) {
+            const WaveSortPtrs WP = {B.ulist, B.dlist, B.segmark, B.stk};
+            wave_std_sort<SRec, Cmp, 0>(B.rec, cnt, Cmp(), WP, lane);
+        } else {
+            if (lane == 0) gs_std_sort<SRec>(B.rec, cnt, Cmp());   // beyond the 16-bit stop lists: one lane
+        }
+        WAVE_SYNC();
+    }
+}
+
+__device__ __forceinline__ bool flow_abort(const FlowArrays& F) { return ag_ld(&F.ctrl[1]) != 0; }
+__device__ __forceinline__ void flow_fail(const FlowArrays& F, int32_t st) { __hip_atomic_fetch_max(&F.ctrl[1], st, RLX, AGT); }
+
+// chunk `c` of column k: its base from the directory, allocated by whoever asks first (others wait for the word)
+__device__ __forceinline__ int32_t flow_chunk_base(const Arrays& A, const FlowArrays& F, int32_t k, int c, int32_t spin_limit) {
+    int32_t* word;
+    if (c < FDIR - 1) word = F.cdir + (int64_t)k * FDIR + c;
+    else {
+        int32_t* ow = F.cdir + (int64_t)k * FDIR + (FDIR - 1);
+        int32_t ob = ag_ld(ow);
+        if (ob == FD_EMPTY) {
+            int32_t seen = FD_EMPTY;
+            if (__hip_atomic_compare_exchange_strong(ow, &seen, FD_BUSY, RLX, RLX, AGT)) {
+                int32_t base = ag_add(A.pool_top, FDIR_OVF_SLOTS);
+                if (base < 0 || base > A.slot_cap - FDIR_OVF_SLOTS) { flow_fail(F, ST_POOL_OVERFLOW); base = FD_FAIL; }
+                else {
+                    int32_t* o = reinterpret_cast<int32_t*>(A.e + base);
+                    for (int q = 0; q < FDIR_OVF; ++q) ag_st(o + q, FD_EMPTY);
+                    DRAIN_STORES();
+                }
+                ag_st(ow, base);
+                ob = base;
+            } else ob = seen;
+        }
+        for (int sp = 0; ob == FD_BUSY; ++sp) {
+            __builtin_amdgcn_s_sleep(2);
+            ob = ag_ld(ow);
+            if (sp > spin_limit) { flow_fail(F, ST_INTERNAL); return FD_FAIL; }
+        }
+        if (ob < 0) return FD_FAIL;
+        word = reinterpret_cast<int32_t*>(A.e + ob) + (c - (FDIR - 1));
+    }
+    int32_t b = ag_ld(word);
+    if (b == FD_EMPTY) {
+        int32_t seen = FD_EMPTY;
+        if (__hip_atomic_compare_exchange_strong(word, &seen, FD_BUSY, RLX, RLX, AGT)) {
+            const int32_t need = 1 + chunk_cap(c);
+            int32_t base = ag_add(A.pool_top, need);
+            if (base < 0 || base > A.slot_cap - need) { flow_fail(F, ST_POOL_OVERFLOW); base = FD_FAIL; }
+            ag_st(word, base);
+            b = base;
+        } else b = seen;
+    }
+    for (int sp = 0; b == FD_BUSY; ++sp) {
+        __builtin_amdgcn_s_sleep(2);
+        b = ag_ld(word);
+        if (sp > spin_limit) { flow_fail(F, ST_INTERNAL); return FD_FAIL; }
+    }
+    return b < 0 ? FD_FAIL : b;
+}
+
+#define FLOW_JITTER(tag) do { if (P.jitter > 0) { const uint32_t _h = ((uint32_t)idx * 2654435761u + (uint32_t)(tag) * 40503u) >> 9; \
+        if ((_h & 3u) == 0u) for (int _q = 0; _q < P.jitter * (int)(1 + ((_h >> 2) & 7u)); ++_q) __builtin_amdgcn_s_sleep(8); } } while (0)
+
+// One position of the order, from the gathered column to the release of the neighbours.  `ext` slots are read (appended + CSR,
+// dead ones included); the live ones must fit `cap`.  Returns false when the launch is being abandoned.
+template <int ON, class BUF>
+__device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays& F, const FlowParams& P, BUF& B, const int32_t cap,
+                                               const int32_t idx, const int32_t v, const int32_t cp0, const int32_t cp1, const int32_t acnt,
+                                               const int32_t g, const int32_t vbase, const uint64_t gseed, int32_t* last_draws) {
+    const int lane = lane_id();
+    const uint64_t lt = lanemask_lt(lane);
+    // ---- gather (:616-639) in physical order: appended index descending, then the CSR segment descending ----
+    int len0 = 0, napp = 0;
+    {
+        int32_t dirbase = FD_EMPTY;
+        if (acnt > 0) {
+            const int ct = chunk_of(acnt - 1);
+            if (lane <= ct) {
+                if (lane < FDIR - 1) dirbase = ag_ld(F.cdir + (int64_t)v * FDIR + lane);
+                else { const int32_t ob = ag_ld(F.cdir + (int64_t)v * FDIR + (FDIR - 1)); dirbase = ob >= 0 ? ag_ld(reinterpret_cast<const int32_t*>(A.e + ob) + (lane - (FDIR - 1))) : FD_FAIL; }
+            }
+        }
+        for (int32_t i0 = acnt - 1; i0 >= 0; i0 -= 64) {
+            const int32_t i = i0 - lane;
+            const bool valid = i >= 0;
+            const int c = valid ? chunk_of(i) : 0;
+            const int32_t base = __shfl(dirbase, c);
+            double val = 0; int32_t nb = 0, tw = 0, tg = 0;
+            if (valid && base >= 0) {
+                const int32_t s = base + 1 + (i - chunk_start(c));
+                const Slot gsl = ag_ld_slot(A.e + s);
+                val = gsl.val; nb = gsl.nbr; tw = gsl.twin; tg = ag_ld(F.atag + s);
+            }
+            const bool live = valid && val > 0;
+            const uint64_t mask = __ballot(live);
+            const int pos = len0 + popc64(mask & lt);
+            if (live && pos < cap) { B.a_nbr[pos] = nb; B.a_val[pos] = val; B.a_twin[pos] = tw; B.a_tag[pos] = tg; }
+            len0 += popc64(mask);
+        }
+        napp = len0;
+        for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
+            const int32_t s = s0 - lane;
+            const bool valid = s >= cp0;
+            double val = 0; int32_t nb = 0, tw = 0;
+            if (valid) { const Slot gsl = ag_ld_slot(A.e + s); val = gsl.val; nb = gsl.nbr; tw = gsl.twin; }
+            const bool live = valid && val > 0;
+            const uint64_t mask = __ballot(live);
+            const int pos = len0 + popc64(mask & lt);
+            if (live && pos < cap) { B.a_nbr[pos] = nb; B.a_val[pos] = val; B.a_twin[pos] = tw; B.a_tag[pos] = -1; }
+            len0 += popc64(mask);
+        }
+    }
+    if (len0 > cap) { flow_fail(F, ST_INTERNAL); return false; }
+    WAVE_SYNC();
+
+    // ---- sort by neighbour id (std::sort semantics, :641-644) ----
+    for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
+    WAVE_SYNC();
+    flow_sort<false>(B, len0, lane);
+    {   // equal ids: the list order is part of the result -- appended entries newest first (descending tag), then sort again
+        bool dup = false;
+        for (int p = lane + 1; p < len0; p += 64) dup |= (B.rec[p].key == B.rec[p - 1].key);
+        if (__ballot(dup) != 0ull && napp > 1) {
+            for (int i = lane; i < napp; i += 64) B.skey[i] = -(double)B.a_tag[i];
+            WAVE_SYNC();
+            flow_sort<false>(B, napp, lane);   // distinct keys
+            for (int i = lane; i < napp; i += 64) { const int s = B.rec[i].idx; B.b_nbr[i] = B.a_nbr[s]; B.b_twin[i] = B.a_twin[s]; B.b_val[i] = B.a_val[s]; }
+            WAVE_SYNC();
+            for (int i = lane; i < napp; i += 64) { B.a_nbr[i] = B.b_nbr[i]; B.a_twin[i] = B.b_twin[i]; B.a_val[i] = B.b_val[i]; }
+            WAVE_SYNC();
+            for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
+            WAVE_SYNC();
+            flow_sort<false>(B, len0, lane);
+        }
+    }
+
+    // ---- merge multi-edges (:646-659): the first of a run keeps its twin and takes the sum (in sorted order), the others' twins die ----
+    int m = 0, nk = 0;
+    for (int p0 = 0; p0 < len0; p0 += 64) {
+        const int p = p0 + lane;
+        const bool act = p < len0;
+        const int src = act ? B.rec[p].idx : 0;
+        const int32_t nb = act ? B.a_nbr[src] : -1;
+        const int32_t nbprev = (act && p > 0) ? B.a_nbr[B.rec[p - 1].idx] : -2;
+        const bool head = act && nb != nbprev;
+        const uint64_t mask = __ballot(head), kmask = __ballot(act && !head);
+        if (head) {
+            const int x = m + popc64(mask & lt);
+            double val = B.a_val[src];
+            int d = 0;
+            for (int q = p + 1; q < len0 && B.a_nbr[B.rec[q].idx] == nb; ++q) { val += B.a_val[B.rec[q].idx]; ++d; }
+            B.b_nbr[x] = nb; B.b_twin[x] = B.a_twin[src]; B.b_val[x] = val; B.b_dup[x] = d;
+            B.b_pos[x] = A.vr[nb].pqpos;   // (positions never change in a launch: a plain load)
+        } else if (act) {
+            B.a_tag[nk + popc64(kmask & lt)] = B.a_twin[src];
+        }
+        m += popc64(mask); nk += popc64(kmask);
+    }
+    const int32_t cdraw = m > 1 ? m - 1 : 0;
+    if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)cdraw);   // my count: later positions can look past me now
+    WAVE_SYNC();
+    FLOW_JITTER(1);
+
+    // ---- order the neighbours by o_n (:661-673) ----
+    if (ON == ON_RANDOM) {
+        const uint64_t kb = keyed_order_base(gseed, v - vbase, 0);
+        for (int i = lane; i < m; i += 64) B.skey[i] = keyed_order_dkey(kb, B.b_nbr[i] - vbase);
+    } else {
+        for (int i = lane; i < m; i += 64) B.skey[i] = B.b_val[i];
+    }
+    WAVE_SYNC();
+    flow_sort<ON == ON_DESC>(B, m, lane);
+    for (int j = lane; j < m; j += 64) {
+        const int x = B.rec[j].idx;
+        B.a_nbr[j] = B.b_nbr[x]; B.a_val[j] = B.b_val[x]; B.a_twin[j] = B.b_twin[x]; B.f_dup[j] = B.b_dup[x]; B.f_pos[j] = B.b_pos[x];
+    }
+    WAVE_SYNC();
+
+    // ---- cumulative weights and the f / colScale / wdeg recurrence (:728-779): one lane, the operation order is the result ----
+    double* cum = B.cum();
+    double* newv = B.newv();
+    if (lane == 0) {
+        double csum = 0;
+        for (int j0 = 0; j0 < m; j0 += 8) {
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = (j0 + u < m) ? B.a_val[j0 + u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j0 + u < m) { csum += vv[u]; cum[j0 + u] = csum; }
+        }
+        double wdeg = csum, colScale = 1;
+        for (int j0 = 0; j0 < m - 1; j0 += 8) {
+            double vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = (j0 + u < m - 1) ? B.a_val[j0 + u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j0 + u < m - 1) {
+                    const double w = vv[u] * colScale;
+                    const double f = w / wdeg;
+                    const double omf = 1 - f;
+                    newv[j0 + u] = f * omf * wdeg;
+                    colScale = colScale * omf;
+                    wdeg = wdeg * omf * omf;
+                }
+            }
+        }
+    }
+    WAVE_SYNC();
+
+    // ---- uniform offset: decoupled look-back over the published counts (the stream is consumed in order, :729) ----
+    long long D = 0;
+    {
+        long long sum = 0;
+        int32_t hi = idx - 1;   // highest position not yet added
+        int spins = 0;
+        while (true) {
+            const int32_t q = hi - lane;
+            unsigned long long wv = LB_VALID | LB_PREFIX;   // below the array: never reached (a sentinel stops the walk)
+            if (q >= 0) wv = ag_ld64(F.lb + q);
+            const uint64_t pm = __ballot((wv & LB_PREFIX) != 0ull && (wv & LB_VALID) != 0ull);
+            const uint64_t vm = __ballot((wv & LB_VALID) != 0ull);
+            const int stop = pm ? __builtin_ctzll(pm) : 64;               // nearest inclusive prefix, in lanes
+            const uint64_t need = stop >= 63 ? ~0ull : ((2ull << stop) - 1ull);
+            if ((vm & need) == need) {
+                long long part = (lane <= stop) ? (long long)(wv & LB_MASK) : 0ll;
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+                sum += part;
+                if (pm) break;
+                hi -= 64;
+                continue;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63) == 0 && flow_abort(F)) return false;
+            if (spins > P.spin_limit) { flow_fail(F, ST_INTERNAL); return false; }
+        }
+        D = sum;
+    }
+    if (D + cdraw > A.rng_len) { flow_fail(F, ST_RNG_OVERFLOW); return false; }
+    if (lane == 0) ag_st64(F.lb + idx, LB_VALID | LB_PREFIX | (unsigned long long)(D + cdraw));
+    *last_draws = (int32_t)(D + cdraw);
+    FLOW_JITTER(2);
+
+    // ---- sample k for every position but the last (:747-756) ----
+    const double csum = m > 0 ? cum[m - 1] : 0.0;
+    for (int j = lane; j < m - 1; j += 64) {
+        const double u = A.rng[D + j];
+        const double cj = cum[j];
+        const double r = u * (csum - cj) + cj;
+        B.ksel[j] = upper_index(cum, m, r);
+    }
+    WAVE_SYNC();
+
+    // ---- commit (:766-776): the new entry is appended to column k, the twin rewritten in place; live pairs are counted at the end that
+    //      comes later; then my last neighbour's entry and the merged duplicates' twins die (:791-792, :655) ----
+    bool failed = false;
+    for (int j0 = 0; j0 < m - 1; j0 += 64) {
+        const int j = j0 + lane;
+        const bool act = j < m - 1;
+        int32_t k = 0, a = 0, s_r = 0, pa = 0, pk = 0, ai = 0, base = FD_FAIL;
+        int c = 0;
+        double nw = 0;
+        if (act) {
+            const int32_t ks = B.ksel[j];
+            k = B.a_nbr[ks]; pk = B.f_pos[ks];
+            a = B.a_nbr[j]; pa = B.f_pos[j]; s_r = B.a_twin[j]; nw = newv[j];
+            ai = ag_add(&A.vr[k].app_cnt, 1);
+            c = chunk_of(ai);
+        }
+        FLOW_JITTER(3 + (lane & 3));
+        if (act) base = flow_chunk_base(A, F, k, c, P.spin_limit);
+        if (act && base >= 0) {
+            const int32_t s_n = base + 1 + (ai - chunk_start(c));
+            ag_st_slot(A.e + s_n, nw, a, s_r);
+            ag_st(F.atag + s_n, (int32_t)(D + j));
+            ag_st_slot(A.e + s_r, nw, k, s_n);
+            if (nw > 0) {
+                if (pk < pa && pa != FPOS_NONE) ag_add(&A.vr[a].key, 1);
+                if (pa < pk && pk != FPOS_NONE) ag_add(&A.vr[k].key, 1);
+            }
+        } else if (act) failed = true;
+    }
+    if (lane == 0 && m >= 1) ag_st_slot_val(A.e + B.a_twin[m - 1], 0.0);
+    for (int i = lane; i < nk; i += 64) ag_st_slot_val(A.e + B.a_tag[i], 0.0);
+    DRAIN_STORES();   // every store and increment of this wave has arrived before a neighbour is released
+    FLOW_JITTER(8);
+    for (int j = lane; j < m; j += 64) {
+        if (B.f_pos[j] != FPOS_NONE) ag_add(&A.vr[B.a_nbr[j]].key, -(1 + B.f_dup[j]));
+    }
+    (void)g;
+    return __ballot(failed) == 0ull;
+}
+
+// ---------------------------------------------------------------------------
+// The persistent kernel: one wave per workgroup; grid = as many as are wanted in flight (they need not all be resident: a
+// workgroup that starts late claims later positions, and what a position waits for is always held by a running wave).
+// ---------------------------------------------------------------------------
+template <int ON, int EC>
+__global__ __launch_bounds__(64) void k_eliminate_flow(Arrays A, FlowArrays F, FlowParams P) {
+    __shared__ FlowLds<EC> L;
+    const int lane = lane_id();
+    if (P.poison >= 0) {
+        uint32_t* const w = reinterpret_cast<uint32_t*>(&L);
+        const uint32_t pat = 0x01010101u * (uint32_t)(P.poison & 0xFF);
+        for (size_t q = lane; q < sizeof(L) / 4; q += 64) w[q] = pat;
+        WAVE_SYNC();
+    }
+    {   // rejected input (the setup kernels' flags are read here, not on the host): nothing is eliminated
+        int32_t bad = 0;
+        if (P.in_flags[FLAG_RANGE]) bad = ST_INDEX_RANGE;
+        else if (P.in_flags[FLAG_CROSS] || P.in_flags[FLAG_PERM]) bad = ST_BAD_ARG;
+        else if (P.in_acc[2] != 0.0 || !(P.in_acc[0] <= 1e-24 * P.in_acc[1])) bad = ST_NOT_SYMMETRIC;
+        if (bad) { if (lane == 0 && blockIdx.x == 0) flow_fail(F, bad); return; }
+    }
+    while (true) {
+        int32_t idx = 0;
+        if (lane == 0) idx = ag_add(&F.ctrl[0], 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= F.Q) break;
+        const int32_t v = F.qv[idx];
+        if (v < 0) continue;   // a graph's sentinel
+        if (flow_abort(F)) break;
+        // ---- wait until every earlier neighbour has committed ----
+        {
+            int spins = 0;
+            int32_t pend = 1;
+            while (true) {
+                if (lane == 0) pend = ag_ld(&A.vr[v].key);
+                pend = __builtin_amdgcn_readfirstlane(pend);
+                if (pend == 0) break;
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                if ((spins & 63) == 0 && flow_abort(F)) { pend = -1; break; }
+                if (spins > P.spin_limit) { flow_fail(F, ST_INTERNAL); pend = -1; break; }
+            }
+            if (pend != 0) break;
+        }
+        const int32_t g = F.qg[idx];
+        const int32_t vbase = P.gd[g].vbase;
+        const uint64_t gseed = A.shuffle_seed + (uint64_t)g;
+        const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
+        int32_t acnt = 0;
+        if (lane == 0) acnt = ag_ld(&A.vr[v].app_cnt);
+        acnt = __builtin_amdgcn_readfirstlane(acnt);
+        const int32_t ext = (cp1 - cp0) + acnt;
+        int32_t draws = 0;
+        bool ok;
+        if (ext <= EC) {
+            ok = flow_eliminate<ON>(A, F, P, L, EC, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+        } else {
+            // long column: working storage from the bump allocator; the sort records and stop lists stay in LDS while they fit
+            int32_t b0 = 0;
+            const int32_t want = ext + 8;
+            if (lane == 0) b0 = ag_add(&F.ctrl[2], want);
+            b0 = __builtin_amdgcn_readfirstlane(b0);
+            if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); break; }
+            char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
+            FlowGlob Gb;
+            const int64_t n8 = want;
+            double* d = reinterpret_cast<double*>(base);
+            Gb.a_val = d; Gb.b_val = d + n8; Gb.skey = d + 2 * n8; Gb.cum_ = d + 3 * n8; Gb.newv_ = d + 4 * n8;
+            int32_t* ip = reinterpret_cast<int32_t*>(d + 5 * n8);
+            Gb.a_nbr = ip; Gb.a_twin = ip + n8; Gb.a_tag = ip + 2 * n8; Gb.b_nbr = ip + 3 * n8; Gb.b_twin = ip + 4 * n8; Gb.b_dup = ip + 5 * n8;
+            Gb.b_pos = ip + 6 * n8; Gb.f_dup = ip + 7 * n8; Gb.f_pos = ip + 8 * n8; Gb.ksel = ip + 9 * n8;
+            constexpr size_t LDS_FREE = offsetof(FlowLds<EC>, stk);                 // everything in front of the segment stack
+            constexpr int BIGL = (int)((LDS_FREE - 64) / 21) & ~7;                  // records + two 16-bit lists + marks per entry
+            constexpr size_t OFF_U = (size_t)BIGL * 16, OFF_D = OFF_U + 2 * (size_t)(BIGL + 2), OFF_M = (OFF_D + 2 * (size_t)(BIGL + 2) + 3) & ~(size_t)3;
+            static_assert(OFF_M + 4 * (size_t)(BIGL / 32 + 2) <= LDS_FREE, "the long-column sort does not fit the wave's LDS");
+            if (FLOW_BIG_IN_LDS && ext <= BIGL) {
+                char* lb = reinterpret_cast<char*>(&L);
+                Gb.rec = reinterpret_cast<SRec*>(lb);
+                Gb.ulist = reinterpret_cast<uint16_t*>(lb + OFF_U);
+                Gb.dlist = reinterpret_cast<uint16_t*>(lb + OFF_D);
+                Gb.segmark = reinterpret_cast<uint32_t*>(lb + OFF_M);
+                Gb.stk = L.stk;
+            } else {
+                // everything in global scratch: records behind the ints, lists behind the records (want + 8 entries each)
+                char* q = reinterpret_cast<char*>(ip + 10 * n8);
+                // 16-byte alignment of the records: 5 * 8 * n8 + 10 * 4 * n8 = 80 * n8 bytes in front
+                Gb.rec = reinterpret_cast<SRec*>(q);
+                Gb.ulist = reinterpret_cast<uint16_t*>(q + 16 * n8);
+                Gb.dlist = Gb.ulist + n8;
+                Gb.segmark = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(Gb.dlist + n8));
+                Gb.stk = L.stk;
+            }
+            ok = flow_eliminate<ON>(A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+            if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[3], 1, RLX, AGT);
+        }
+        if (!ok) break;
+        // the last position of a graph files the graph's draw count
+        if (lane == 0 && (idx + 1 >= F.Q || F.qv[idx + 1] < 0)) P.gd[g].n_draws = draws;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// setup: positions, queue, sentinels, pending counters
+// ---------------------------------------------------------------------------
+__global__ void k_flow_queue(const int64_t* __restrict__ perm, const int32_t* __restrict__ vgraph, const GraphDesc* __restrict__ gd, int32_t N,
+                             VRec* __restrict__ vr, int32_t* __restrict__ qv, int32_t* __restrict__ qg, unsigned long long* __restrict__ lb) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t g = vgraph[i];
+    const GraphDesc& D = gd[g];
+    const int32_t idx = i - D.vbase;             // place in the node_id vector
+    const int64_t p = (int64_t)D.n - 1 - idx;    // pop number (:609 pops from the back)
+    int64_t pl = perm[i];
+    if (pl < 0 || pl >= (int64_t)D.n) pl = 0;    // (flagged by k_perm_check: nothing is eliminated then)
+    const int32_t v = D.vbase + (int32_t)pl;
+    if (p < D.n_elim) {
+        const int32_t li = D.flow_base + 1 + (int32_t)p;
+        qv[li] = v; qg[li] = g; lb[li] = 0ull;
+        vr[v].pqpos = li;
+    }
+    if (idx == 0) { qv[D.flow_base] = -1; qg[D.flow_base] = g; lb[D.flow_base] = LB_VALID | LB_PREFIX; }
+}
+__global__ void k_flow_qinit(int32_t* __restrict__ qv, int32_t* __restrict__ qg, unsigned long long* __restrict__ lb, int32_t Q) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Q) { qv[i] = -1; qg[i] = 0; lb[i] = LB_VALID | LB_PREFIX; }   // every word starts as a sentinel (prefix 0)
+}
+__global__ void k_flow_vinit(VRec* __restrict__ vr, int32_t* __restrict__ cdir, int32_t N) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    vr[i].key = 0; vr[i].pqpos = FPOS_NONE;
+    int4* d = reinterpret_cast<int4*>(cdir + (int64_t)i * FDIR);
+    d[0] = make_int4(FD_EMPTY, FD_EMPTY, FD_EMPTY, FD_EMPTY); d[1] = make_int4(FD_EMPTY, FD_EMPTY, FD_EMPTY, FD_EMPTY);
+    static_assert(FDIR == 8, "two 16-byte stores per directory");
+}
+// pend[a] = live entries (u -> a) in columns of vertices u that are eliminated before a
+__global__ void k_flow_pending(const Slot* __restrict__ ent, const int32_t* __restrict__ slot_col, const int32_t* __restrict__ nnz_p, VRec* __restrict__ vr) {
+    const int32_t nnz = *nnz_p;
+    for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < nnz; s += gridDim.x * blockDim.x) {
+        const Slot e = ent[s];
+        if (!(e.val > 0)) continue;
+        const int32_t pu = vr[slot_col[s]].pqpos, pa = vr[e.nbr].pqpos;
+        if (pu < pa && pa != FPOS_NONE) atomicAdd(&vr[e.nbr].key, 1);
+    }
+}
+// afterwards: header links + VRec::app_chunk (the layout the output pass reads), per-graph status
+__global__ void k_flow_finish(Arrays A, FlowArrays F, GraphDesc* __restrict__ gd, int32_t N, int32_t G) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flow_finish_vertex(A, F, i);
+    if (i < G) {
+        const int32_t st = F.ctrl[1];
+        if (st) gd[i].status = st;
+        gd[i].pad0 = 0; gd[i].pad1 = (i == 0) ? F.ctrl[3] : 0;   // ("rounds" has no meaning here; "singles" = long columns)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// tag order of the surviving columns (rlap_flow.h): concurrent eliminations push into a column out of order; the output pass
+// (:789-810 with compressColumnSC :678-711) reads the list newest first.  Columns whose appended entries are not in tag order are
+// sorted: one (column, tag) radix sort over their entries, then a permutation through a copy.  (Twins are not kept: nothing
+// reads them after the elimination.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int32_t flow_slot_plain(const Arrays& A, const FlowArrays& F, int32_t v, int32_t i) {
+    const int c = chunk_of(i);
+    const int32_t base = c < FDIR - 1 ? F.cdir[(int64_t)v * FDIR + c] : reinterpret_cast<const int32_t*>(A.e + F.cdir[(int64_t)v * FDIR + FDIR - 1])[c - (FDIR - 1)];
+    return base + 1 + (i - chunk_start(c));
+}
+__global__ void k_flow_ro_count(Arrays A, FlowArrays F, const uint32_t* __restrict__ order, int32_t S, int32_t* __restrict__ cnt) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > S) return;
+    if (i == S) { cnt[S] = 0; return; }
+    const int32_t v = (int32_t)order[i];
+    const int32_t acnt = A.vr[v].app_cnt;
+    int32_t c = 0;
+    if (acnt >= 2) {
+        c = acnt;
+        if (acnt <= 48) {   // short: look (most columns are in order already)
+            bool sorted = true;
+            int32_t prev = F.atag[flow_slot_plain(A, F, v, 0)];
+            for (int32_t q = 1; q < acnt; ++q) { const int32_t t = F.atag[flow_slot_plain(A, F, v, q)]; sorted &= t > prev; prev = t; }
+            if (sorted) c = 0;
+        }
+    }
+    cnt[i] = c;
+}
+__global__ void k_flow_ro_emit(Arrays A, FlowArrays F, const uint32_t* __restrict__ order, int32_t S, const int32_t* __restrict__ off,
+                               uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ home, int32_t cap, int32_t* __restrict__ status) {
+    const int32_t M = off[S];
+    if (M > cap) { if (blockIdx.x == 0 && threadIdx.x == 0 && *status == 0) *status = ST_FLOW_REORDER; return; }
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < cap; r += gridDim.x * blockDim.x) {
+        if (r >= M) { keys[r] = ~0ull; vals[r] = 0u; continue; }   // (the sort runs over the whole buffer: its length is a host-side argument)
+        int32_t lo = 0, hi = S;   // last i with off[i] <= r
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (off[mid] <= r) lo = mid; else hi = mid; }
+        const int32_t v = (int32_t)order[lo];
+        const int32_t s = flow_slot_plain(A, F, v, r - off[lo]);
+        keys[r] = ((uint64_t)(uint32_t)lo << 32) | (uint32_t)F.atag[s];
+        vals[r] = (uint32_t)s; home[r] = (uint32_t)s;
+    }
+}
+__global__ void k_flow_ro_fetch(Arrays A, const int32_t* __restrict__ off, int32_t S, const uint32_t* __restrict__ sorted_slot, int32_t cap, Slot* __restrict__ tmp) {
+    const int32_t M = off[S];
+    if (M > cap) return;
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < M; r += gridDim.x * blockDim.x) tmp[r] = A.e[sorted_slot[r]];
+}
+__global__ void k_flow_ro_store(Arrays A, FlowArrays F, const int32_t* __restrict__ off, int32_t S, const uint32_t* __restrict__ home, const uint64_t* __restrict__ sorted_keys,
+                                int32_t cap, const Slot* __restrict__ tmp) {
+    const int32_t M = off[S];
+    if (M > cap) return;
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < M; r += gridDim.x * blockDim.x) { A.e[home[r]] = tmp[r]; F.atag[home[r]] = (int32_t)(uint32_t)(sorted_keys[r] & 0xFFFFFFFFull); }
+}
+
+template <int EC>
+static void launch_flow_t(int o_n, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
+    if (o_n == ON_ASC) hipLaunchKernelGGL((k_eliminate_flow<ON_ASC, EC>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    else if (o_n == ON_DESC) hipLaunchKernelGGL((k_eliminate_flow<ON_DESC, EC>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    else hipLaunchKernelGGL((k_eliminate_flow<ON_RANDOM, EC>), dim3(grid), dim3(64), 0, stream, A, F, P);
+}
+
+void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p,
+                       int32_t N, int64_t Eeff) {
+    const unsigned nb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_flow_qinit, dim3((unsigned)((F.Q + 255) / 256)), dim3(256), 0, s, const_cast<int32_t*>(F.qv), const_cast<int32_t*>(F.qg), F.lb, F.Q);
+    hipLaunchKernelGGL(k_flow_vinit, dim3(nb), dim3(256), 0, s, A.vr, F.cdir, N);
+    hipLaunchKernelGGL(k_flow_queue, dim3(nb), dim3(256), 0, s, A.perm, P.vgraph, P.gd, N, A.vr, const_cast<int32_t*>(F.qv), const_cast<int32_t*>(F.qg), F.lb);
+    if (Eeff > 0) {
+        const unsigned ne = (unsigned)std::min<int64_t>((Eeff + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_flow_pending, dim3(ne), dim3(256), 0, s, A.e, slot_col, nnz_p, A.vr);
+    }
+}
+
+void launch_flow_eliminate(int o_n, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
+    launch_flow_t<FLOW_EC>(o_n, grid, stream, A, F, P);
+}
+
+void launch_flow_finish(hipStream_t s, const Arrays& A, const FlowArrays& F, GraphDesc* gd, int32_t N, int32_t G) {
+    const int32_t n = N > G ? N : G;
+    hipLaunchKernelGGL(k_flow_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, F, gd, N, G);
+}
+
+void launch_flow_ro_count(hipStream_t s, const Arrays& A, const FlowArrays& F, const uint32_t* order, int32_t S, int32_t* cnt) {
+    hipLaunchKernelGGL(k_flow_ro_count, dim3((unsigned)((S + 1 + 255) / 256)), dim3(256), 0, s, A, F, order, S, cnt);
+}
+void launch_flow_ro_emit(hipStream_t s, const Arrays& A, const FlowArrays& F, const uint32_t* order, int32_t S, const int32_t* off, uint64_t* keys, uint32_t* vals,
+                         uint32_t* home, int32_t cap, int32_t* status) {
+    hipLaunchKernelGGL(k_flow_ro_emit, dim3(2048), dim3(256), 0, s, A, F, order, S, off, keys, vals, home, cap, status);
+}
+void launch_flow_ro_permute(hipStream_t s, const Arrays& A, const FlowArrays& F, const int32_t* off, int32_t S, const uint32_t* sorted_slot, const uint64_t* sorted_keys,
+                            const uint32_t* home, int32_t cap, Slot* tmp) {
+    hipLaunchKernelGGL(k_flow_ro_fetch, dim3(2048), dim3(256), 0, s, A, off, S, sorted_slot, cap, tmp);
+    hipLaunchKernelGGL(k_flow_ro_store, dim3(2048), dim3(256), 0, s, A, F, off, S, home, sorted_keys, cap, tmp);
+}
+
+}  // namespace rlap

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "rlap_core.h"
+#include "rlap_flow.h"
 
 namespace rlap {
 
@@ -110,6 +111,28 @@ __global__ void k_bucket_bounds(const uint32_t* order, const VRec* vr, const int
 void launch_eq_tables(hipStream_t stream, uint8_t* out);
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
                             int32_t* batch_pos, const int32_t* flags, const double* acc, bool wide);
+// ---- dataflow elimination for o_v = random (rlap_flow.hip) ----
+constexpr int FLOW_EC = 448;              // column extent a wave handles in its own LDS (four one-wave workgroups per CU)
+constexpr int FLOW_SCR_BYTES = 104;       // working storage per entry of a longer column (bump-allocated, rlap_flow.hip)
+struct FlowParams {
+    const int32_t* vgraph;
+    GraphDesc* gd;
+    const int32_t* in_flags;
+    const double* in_acc;
+    char* scr;               // long columns: bump-allocated working storage (FLOW_SCR_BYTES per entry)
+    int32_t scr_entries;
+    int32_t spin_limit;      // polls (with s_sleep) a wait may take before the launch gives up with ST_INTERNAL
+    int32_t jitter;          // debug: waves sleep at the phase boundaries (schedule perturbation)
+    int32_t poison;          // debug: LDS starts as this byte
+};
+void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int64_t Eeff);
+void launch_flow_eliminate(int o_n, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P);
+void launch_flow_finish(hipStream_t s, const Arrays& A, const FlowArrays& F, GraphDesc* gd, int32_t N, int32_t G);
+void launch_flow_ro_count(hipStream_t s, const Arrays& A, const FlowArrays& F, const uint32_t* order, int32_t S, int32_t* cnt);
+void launch_flow_ro_emit(hipStream_t s, const Arrays& A, const FlowArrays& F, const uint32_t* order, int32_t S, const int32_t* off, uint64_t* keys, uint32_t* vals,
+                         uint32_t* home, int32_t cap, int32_t* status);
+void launch_flow_ro_permute(hipStream_t s, const Arrays& A, const FlowArrays& F, const int32_t* off, int32_t S, const uint32_t* sorted_slot, const uint64_t* sorted_keys,
+                            const uint32_t* home, int32_t cap, Slot* tmp);
 __global__ void k_sc_keys(const VRec* vr, const int32_t* origpos, const int32_t* vgraph, const GraphDesc* gd,
                           int32_t N, uint64_t* skey, uint32_t* sval);
 __global__ void k_sc_perm_order(const int64_t* perm, const int32_t* vgraph, const GraphDesc* gd, const int64_t* surv_base, int32_t N,

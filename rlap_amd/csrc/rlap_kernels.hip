@@ -22,15 +22,10 @@
 
 #include "rlap_core.h"
 #include "rlap_kernels.h"
+#include "rlap_wave_sort.h"
 
 namespace rlap {
 
-// ---------------------------------------------------------------------------
-// small wave helpers (wave64)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return lane == 0 ? 0ull : (~0ull >> (64 - lane)); }
-__device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 
 // This file is compiled twice (Makefile).  rlap_kernels.o has everything but the priority-queue instantiations of the elimination
 // kernel; rlap_kernels_pq.o (-DRLAP_ELIM_PQ_TU -mllvm -disable-machine-licm) has only those: with machine LICM the invariants that get
@@ -390,610 +385,6 @@ __global__ void k_bucket_bounds(const uint32_t* __restrict__ order, const VRec* 
 // beyond n) go through the single-vertex wave path or the sequential fallback.
 // ---------------------------------------------------------------------------
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void*)(p)))   // out-of-line functions see generic pointers otherwise
-#else
-#define ASSUME_LDS(p) ((void)0)
-#endif
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-
-// ---------------------------------------------------------------------------
-// Wave-parallel restatement of libstdc++'s std::sort (same permutation under ties as
-// rlap_core.h::gs_std_sort, which is the sequential restatement).  One wave, data in LDS.
-//   * introsort loop: the unguarded Hoare partition is done by the whole wave.  The up-scan stops at
-//     the positions with !(x < pivot), the down-scan at those with !(pivot < x); the t-th up-stop is
-//     swapped with the t-th down-stop while it lies to its left, and swapped elements are never
-//     looked at again, so both stop lists can be taken from the array as it is before the swaps.
-//     With k swaps, the cut is min(u_k, d_{k-1}).
-//   * final insertion sort == independent stable sorts of the <=16-element segments the loop leaves
-//     (everything left of a cut is <= everything right of it), one lane per segment.
-// Scratch per wave: two uint16 lists of n entries, n bits of segment marks, a small segment stack.
-// ---------------------------------------------------------------------------
-template <int CAP>
-struct WaveSortScratchT {
-    uint16_t ulist[CAP + 2];
-    uint16_t dlist[CAP + 2];
-    uint32_t segmark[(CAP + 31) / 32 + 1];
-    int32_t stk[3 * 48];
-};
-typedef WaveSortScratchT<SCAP> WaveSortScratch;
-
-struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; };
-
-// REGT > 0: arrays of at most 64*REGT elements run the final phase with one lane per ELEMENT, the elements held
-// in registers between the rank computation and the stores (no second buffer).
-template <class T, class Less, int REGT = 0>
-__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane, T* obuf = nullptr) {
-    struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
-    if (n < 2) return;
-    const uint64_t lt = lanemask_lt(lane);
-    for (int q = lane; q < (n + 31) / 32 + 1; q += 64) W.segmark[q] = 0u;
-    WAVE_SYNC();
-    if (n <= 16) {
-        if (lane == 0) gs_insertion_sort<T>(a, n, less);
-        WAVE_SYNC();
-        return;
-    }
-    int depth0 = 0;
-    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
-    depth0 *= 2;
-    int sp = 0;
-    if (lane == 0) { W.stk[0] = 0; W.stk[1] = n; W.stk[2] = depth0; }
-    sp = 1;
-    WAVE_SYNC();
-    while (sp > 0) {
-        --sp;
-        int first = W.stk[3 * sp], last = W.stk[3 * sp + 1], depth = W.stk[3 * sp + 2];
-        bool heap_sorted = false;
-        while (last - first > 16) {
-            if (depth == 0) {
-                if (lane == 0) gs_heap_sort<T>(a, first, last, less);
-                WAVE_SYNC();
-                heap_sorted = true;
-                break;
-            }
-            --depth;
-            // __move_median_to_first(first, first+1, mid, last-1), by one lane
-            if (lane == 0) {
-                int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
-                int pick;
-                if (less(a[ia], a[ib])) {
-                    if (less(a[ib], a[ic])) pick = ib;
-                    else if (less(a[ia], a[ic])) pick = ic;
-                    else pick = ia;
-                } else if (less(a[ia], a[ic])) pick = ia;
-                else if (less(a[ib], a[ic])) pick = ic;
-                else pick = ib;
-                T t = a[first]; a[first] = a[pick]; a[pick] = t;
-            }
-            WAVE_SYNC();
-            const T pv = a[first];
-            // stop lists of the two scans over [first+1, last)
-            int nu = 0, nd = 0;
-            for (int p0 = first + 1; p0 < last; p0 += 64) {
-                int p = p0 + lane;
-                bool stop = (p < last) && !less(a[p], pv);
-                uint64_t mk = __ballot(stop);
-                if (stop) W.ulist[nu + popc64(mk & lt)] = (uint16_t)p;
-                nu += popc64(mk);
-            }
-            for (int p0 = last - 1; p0 > first; p0 -= 64) {
-                int p = p0 - lane;
-                bool stop = (p > first) && !less(pv, a[p]);
-                uint64_t mk = __ballot(stop);
-                if (stop) W.dlist[nd + popc64(mk & lt)] = (uint16_t)p;
-                nd += popc64(mk);
-            }
-            if (lane == 0) W.dlist[nd] = (uint16_t)first;   // the pivot itself stops the down-scan
-            WAVE_SYNC();
-            // number of swaps: pairs (u_t, d_t) with u_t < d_t form a prefix
-            int k = 0;
-            {
-                const int tmax = nu < nd ? nu : nd;
-                bool open = true;
-                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
-                    int t = t0 + lane;
-                    bool ok = (t < tmax) && (W.ulist[t] < W.dlist[t]);
-                    uint64_t mk = __ballot(ok);
-                    // ok is monotone (true...true,false...): count the leading run
-                    uint64_t inv = ~mk;
-                    int run = inv ? __builtin_ctzll(inv) : 64;
-                    k += run;
-                    open = (run == 64);
-                }
-            }
-            T xu, xd;
-            for (int t0 = 0; t0 < k; t0 += 64) {
-                int t = t0 + lane;
-                if (t < k) { xu = a[W.ulist[t]]; xd = a[W.dlist[t]]; }
-                WAVE_SYNC();
-                if (t < k) { a[W.ulist[t]] = xd; a[W.dlist[t]] = xu; }
-                WAVE_SYNC();
-            }
-            int cut;
-            {
-                int cu = (k < nu) ? (int)W.ulist[k] : 0x7FFFFFFF;
-                int cd = (k > 0) ? (int)W.dlist[k - 1] : 0x7FFFFFFF;
-                cut = cu < cd ? cu : cd;
-            }
-            WAVE_SYNC();
-            // recurse on [cut,last), continue with [first,cut)
-            if (last - cut > 16) {
-                if (lane == 0) { W.stk[3 * sp] = cut; W.stk[3 * sp + 1] = last; W.stk[3 * sp + 2] = depth; }
-                ++sp;
-            } else if (lane == 0) {
-                atomicOr(&W.segmark[cut >> 5], 1u << (cut & 31));
-            }
-            WAVE_SYNC();
-            last = cut;
-        }
-        if (lane == 0) atomicOr(&W.segmark[first >> 5], 1u << (first & 31));
-        (void)heap_sorted;
-        WAVE_SYNC();
-    }
-    if (REGT > 0 && n <= 64 * REGT) {
-        T vv[REGT > 0 ? REGT : 1];
-        int rr[REGT > 0 ? REGT : 1];
-#pragma unroll
-        for (int t = 0; t < REGT; ++t) {
-            const int p = lane + 64 * t;
-            rr[t] = -1;
-            if (p < n) {
-                const int w = p >> 5;
-                const uint32_t here = W.segmark[w];
-                const uint32_t lowm = here & (0xFFFFFFFFu >> (31 - (p & 31)));
-                int s0;
-                if (lowm) s0 = w * 32 + 31 - __builtin_clz(lowm);
-                else { int w1 = w - 1; uint32_t bb = W.segmark[w1]; while (bb == 0u) { --w1; bb = W.segmark[w1]; } s0 = w1 * 32 + 31 - __builtin_clz(bb); }
-                const uint32_t highm = ((p & 31) == 31) ? 0u : (here & (0xFFFFFFFFu << ((p & 31) + 1)));
-                int e0 = n;
-                if (highm) e0 = w * 32 + __builtin_ctz(highm);
-                else { for (int w1 = w + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } } }
-                const T v = a[p];
-                int r = s0;
-                for (int q = s0; q < e0; ++q) {
-                    const T x = a[q];
-                    r += (q != p && (less(x, v) || (!less(v, x) && q < p))) ? 1 : 0;
-                }
-                vv[t] = v; rr[t] = r;
-            }
-        }
-        WAVE_SYNC();
-#pragma unroll
-        for (int t = 0; t < REGT; ++t) if (rr[t] >= 0) a[rr[t]] = vv[t];
-        WAVE_SYNC();
-        return;
-    }
-    if (obuf) {
-        // final insertion sort == stable sort of every marked segment (<= 16 elements): one lane per ELEMENT
-        // computes its rank inside its segment and writes it to its place in obuf, then everything is copied back
-        for (int p = lane; p < n; p += 64) {
-            const int w = p >> 5;
-            const uint32_t here = W.segmark[w];
-            const uint32_t lowm = here & (0xFFFFFFFFu >> (31 - (p & 31)));
-            int s0;
-            if (lowm) s0 = w * 32 + 31 - __builtin_clz(lowm);
-            else { int w1 = w - 1; uint32_t bb = W.segmark[w1]; while (bb == 0u) { --w1; bb = W.segmark[w1]; } s0 = w1 * 32 + 31 - __builtin_clz(bb); }
-            const uint32_t highm = ((p & 31) == 31) ? 0u : (here & (0xFFFFFFFFu << ((p & 31) + 1)));
-            int e0 = n;
-            if (highm) e0 = w * 32 + __builtin_ctz(highm);
-            else { for (int w1 = w + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } } }
-            const T v = a[p];
-            int r = s0;
-            for (int q = s0; q < e0; ++q) {
-                const T x = a[q];
-                r += (q != p && (less(x, v) || (!less(v, x) && q < p))) ? 1 : 0;
-            }
-            obuf[r] = v;
-        }
-        WAVE_SYNC();
-        for (int p = lane; p < n; p += 64) a[p] = obuf[p];
-        WAVE_SYNC();
-        return;
-    }
-    // final insertion sort: lane l takes the segments that start in the 32-position words l, l+64, ...
-    for (int w0 = lane; w0 * 32 < n; w0 += 64) {
-        uint32_t bits = W.segmark[w0];
-        while (bits) {
-            const int s0 = w0 * 32 + __builtin_ctz(bits);
-            bits &= bits - 1;
-            int e0 = n;   // end = next mark after s0, or n
-            if (bits) e0 = w0 * 32 + __builtin_ctz(bits);
-            else {
-                for (int w1 = w0 + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } }
-            }
-            for (int i = s0 + 1; i < e0; ++i) {
-                T v = a[i];
-                int j = i - 1;
-                while (j >= s0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
-                a[j + 1] = v;
-            }
-        }
-    }
-    WAVE_SYNC();
-}
-
-// ---------------------------------------------------------------------------
-// Level-synchronous form of the same restatement for n <= 64*REG elements in LDS (element p = lane p%64, turn p/64):
-// every segment of one recursion level is partitioned in the same pass, so a sort costs as many passes as the introsort
-// is deep (both halves of a partition run with the same decremented depth limit, and partitions of disjoint segments do
-// not see each other) instead of one pass per partition.  The segment starts are a bit mask (wave-uniform); the stop
-// lists of a segment are stored at the segment's own offset; ranks inside them are differences of per-position stop counts
-// (ballot popcounts, tabulated in LDS so that a segment reads the counts at its two ends):
-//   up-stop p, `cu` up-stops before it in its segment, `cd` down-stops behind it: it is u_cu and swaps iff d_cu > p
-//   iff cd > cu; a down-stop is d_cd and swaps iff u_cd < p iff cu > cd; with k swaps the cut min(u_k, d_{k-1}) is the
-//   up-stop with cu == k and cd >= k, or the down-stop with cd == k-1 and cu <= k.
-// Returns false when a segment longer than 16 meets depth limit 0 (std::sort heap-sorts it): the array is then
-// partly partitioned and the caller starts over with wave_std_sort on the original order.
-// ---------------------------------------------------------------------------
-template <class T, class Less, int REG>
-__device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* ulist, uint16_t* dlist, uint32_t* tab, uint16_t* tab2, int lane) {
-    if (n < 2) return true;
-    const uint64_t lt = lanemask_lt(lane);
-    const uint64_t le = lt | (1ull << lane);
-    const uint64_t gt = ~le;
-    uint64_t seg[REG];
-#pragma unroll
-    for (int t = 0; t < REG; ++t) seg[t] = 0ull;
-    seg[0] = 1ull;
-    int depth = 0;
-    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth;
-    depth *= 2;
-    int first[REG], last[REG];
-    while (true) {
-        // segment of every element: nearest start at or below / above its position
-        int prevw[REG], nextw[REG];
-        {
-            int run = 0;
-#pragma unroll
-            for (int t = 0; t < REG; ++t) { prevw[t] = run; if (seg[t]) run = 64 * t + 63 - __builtin_clzll(seg[t]); }
-            run = n;
-#pragma unroll
-            for (int t = REG - 1; t >= 0; --t) { nextw[t] = run; if (seg[t]) run = 64 * t + __builtin_ctzll(seg[t]); }
-        }
-        bool act[REG];
-        uint64_t anyact = 0ull;
-#pragma unroll
-        for (int t = 0; t < REG; ++t) {
-            const int p = lane + 64 * t;
-            const uint64_t lo = seg[t] & le, hi = seg[t] & gt;
-            first[t] = lo ? 64 * t + 63 - __builtin_clzll(lo) : prevw[t];
-            last[t] = hi ? 64 * t + __builtin_ctzll(hi) : nextw[t];
-            act[t] = p < n && last[t] - first[t] > 16;
-            anyact |= __ballot(act[t]);
-        }
-        if (!anyact) break;
-        if (depth == 0) return false;
-        --depth;
-        T xn[REG];
-        bool su[REG], sd[REG], moved[REG];
-        uint64_t MU[REG], MD[REG];
-#pragma unroll
-        for (int t = 0; t < REG; ++t) {
-            const int p = lane + 64 * t;
-            su[t] = false; sd[t] = false; moved[t] = false;
-            if (act[t]) {
-                // __move_median_to_first(first, first+1, mid, last-1), then the pivot sits at `first`
-                const int f = first[t], ia = f + 1, ib = f + (last[t] - f) / 2, ic = last[t] - 1;
-                const T A = a[ia], B = a[ib], C = a[ic], F = a[f], X = a[p];
-                int pick; T P;
-                if (less(A, B)) {
-                    if (less(B, C)) { pick = ib; P = B; }
-                    else if (less(A, C)) { pick = ic; P = C; }
-                    else { pick = ia; P = A; }
-                } else if (less(A, C)) { pick = ia; P = A; }
-                else if (less(B, C)) { pick = ic; P = C; }
-                else { pick = ib; P = B; }
-                xn[t] = (p == f) ? P : ((p == pick) ? F : X);
-                moved[t] = (p == f) || (p == pick);
-                su[t] = p > f && !less(xn[t], P);
-                sd[t] = p > f && !less(P, xn[t]);
-            }
-            MU[t] = __ballot(su[t]);
-            MD[t] = __ballot(sd[t]);
-        }
-        // stops in front of every position (up-stops in the low half, down-stops in the high half): a segment reads the
-        // entries at its two ends instead of counting over the masks
-        int cumU = 0, cumD = 0;
-#pragma unroll
-        for (int t = 0; t < REG; ++t) {
-            const int p = lane + 64 * t;
-            if (p < n) tab[p] = (uint32_t)(cumU + popc64(MU[t] & lt)) | ((uint32_t)(cumD + popc64(MD[t] & lt)) << 16);
-            cumU += popc64(MU[t]); cumD += popc64(MD[t]);
-        }
-        const uint32_t tab_n = (uint32_t)cumU | ((uint32_t)cumD << 16);
-        WAVE_SYNC();
-        int cu[REG], cd[REG];
-        bool swu[REG], swd[REG];
-        uint64_t SW[REG];
-        cumU = 0; cumD = 0;
-#pragma unroll
-        for (int t = 0; t < REG; ++t) {
-            swu[t] = false; swd[t] = false; cu[t] = 0; cd[t] = 0;
-            if (act[t]) {
-                const uint32_t x1 = tab[first[t] + 1], xl = (last[t] == n) ? tab_n : tab[last[t]];
-                cu[t] = cumU + popc64(MU[t] & lt) - (int)(x1 & 0xFFFFu);     // up-stops before me in my segment
-                cd[t] = (int)(xl >> 16) - (cumD + popc64(MD[t] & le));        // down-stops behind me
-                swu[t] = su[t] && cd[t] > cu[t];
-                swd[t] = sd[t] && cu[t] > cd[t];
-                if (su[t]) ulist[first[t] + cu[t]] = (uint16_t)(lane + 64 * t);
-                if (sd[t]) dlist[first[t] + cd[t]] = (uint16_t)(lane + 64 * t);
-            }
-            cumU += popc64(MU[t]); cumD += popc64(MD[t]);
-            SW[t] = __ballot(swu[t]);
-        }
-        int cumS = 0;
-#pragma unroll
-        for (int t = 0; t < REG; ++t) {
-            const int p = lane + 64 * t;
-            if (p < n) tab2[p] = (uint16_t)(cumS + popc64(SW[t] & lt));
-            cumS += popc64(SW[t]);
-        }
-        WAVE_SYNC();
-        uint64_t CUT[REG];
-#pragma unroll
-        for (int t = 0; t < REG; ++t) {
-            bool iscut = false;
-            if (act[t]) {
-                const int k = (int)((last[t] == n) ? (uint16_t)cumS : tab2[last[t]]) - (int)tab2[first[t] + 1];   // swaps of my segment
-                iscut = (su[t] && cu[t] == k && cd[t] >= k) || (sd[t] && k >= 1 && cd[t] == k - 1 && cu[t] <= k);
-                int dest = lane + 64 * t;
-                if (swu[t]) dest = dlist[first[t] + cu[t]];
-                if (swd[t]) dest = ulist[first[t] + cd[t]];
-                if (swu[t] || swd[t] || moved[t]) a[dest] = xn[t];
-            }
-            CUT[t] = __ballot(iscut);
-        }
-        WAVE_SYNC();
-#pragma unroll
-        for (int t = 0; t < REG; ++t) seg[t] |= CUT[t];
-    }
-    // final insertion sort == stable order inside every segment (all of them <= 16 elements now)
-    T vv[REG];
-    int rr[REG];
-#pragma unroll
-    for (int t = 0; t < REG; ++t) {
-        const int p = lane + 64 * t;
-        rr[t] = -1;
-        if (p < n) {
-            const T v = a[p];
-            int r = first[t];
-            for (int q = first[t]; q < last[t]; ++q) {
-                const T x = a[q];
-                r += (q != p && (less(x, v) || (!less(v, x) && q < p))) ? 1 : 0;
-            }
-            vv[t] = v; rr[t] = r;
-        }
-    }
-    WAVE_SYNC();
-#pragma unroll
-    for (int t = 0; t < REG; ++t) if (rr[t] >= 0) a[rr[t]] = vv[t];
-    WAVE_SYNC();
-    return true;
-}
-
-// ---------------------------------------------------------------------------
-// The same restatement for n <= 64 with ONE ELEMENT PER LANE (key and source index in registers):
-// partitions exchange elements with ds_bpermute instead of LDS round trips, the two stop lists are
-// rank-indexed lane ids in a 2 x 66 int LDS scratch, the segment marks are one 64-bit mask and the
-// final insertion sort is a stable rank inside each <=16-element segment.  On return lane p holds
-// in `key`/`idx` an arbitrary element; *pos = final position of the element the lane holds, so the caller
-// stores out[*pos] = idx.  Returns false (nothing usable) if the depth limit is hit -- the caller falls
-// back to the sequential restatement (heap-sort branch).
-// ---------------------------------------------------------------------------
-template <bool DESC>
-__device__ __forceinline__ bool wave_sort64(double& key, int& idx, const int n, const int lane, int32_t* tmp, int* pos) {
-    auto less = [](double x, double y) { return DESC ? (x > y) : (x < y); };
-    int32_t* tmpu = tmp;
-    int32_t* tmpd = tmp + 66;
-    int32_t* stk = tmp + 132;   // 3 ints per pending segment, at most 3 pending
-    const uint64_t lt = lanemask_lt(lane);
-    const uint64_t gt = (lane == 63) ? 0ull : (~0ull << (lane + 1));
-    uint64_t segmask = 0ull;
-    bool ok_depth = true;
-    if (n > 16) {
-        int depth0 = 0;
-        for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
-        depth0 *= 2;
-        int sp = 0;
-        int first = 0, last = n, depth = depth0;
-        while (true) {
-            while (last - first > 16) {
-                if (depth == 0) { ok_depth = false; break; }
-                --depth;
-                // __move_median_to_first(first, first+1, mid, last-1)
-                const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
-                const double ka = __shfl(key, ia), kb = __shfl(key, ib), kc = __shfl(key, ic);
-                int pick;
-                if (less(ka, kb)) {
-                    if (less(kb, kc)) pick = ib;
-                    else if (less(ka, kc)) pick = ic;
-                    else pick = ia;
-                } else if (less(ka, kc)) pick = ia;
-                else if (less(kb, kc)) pick = ic;
-                else pick = ib;
-                {
-                    const double kf = __shfl(key, first), kp = __shfl(key, pick);
-                    const int xf = __shfl(idx, first), xp = __shfl(idx, pick);
-                    if (lane == first) { key = kp; idx = xp; }
-                    else if (lane == pick) { key = kf; idx = xf; }
-                }
-                const double pv = __shfl(key, first);
-                const bool inr = lane > first && lane < last;
-                const bool su = inr && !less(key, pv);
-                const bool sd = inr && !less(pv, key);
-                const uint64_t mu = __ballot(su), md = __ballot(sd);
-                const int nu = popc64(mu), nd = popc64(md);
-                const int ru = popc64(mu & lt), rd = popc64(md & gt);
-                if (su) tmpu[ru] = lane;
-                if (sd) tmpd[rd] = lane;
-                if (lane == 0) tmpd[nd] = first;   // the pivot itself stops the down-scan
-                WAVE_SYNC();
-                const int tmax = nu < nd ? nu : nd;
-                const bool okp = (lane < tmax) && (tmpu[lane] < tmpd[lane]);
-                const int k = popc64(__ballot(okp));   // a prefix of the pairs
-                int partner = lane;
-                if (su && ru < k) partner = tmpd[ru];
-                else if (sd && rd < k) partner = tmpu[rd];
-                int cu = 0x7FFFFFFF, cd = 0x7FFFFFFF;
-                if (k < nu) cu = tmpu[k];
-                if (k > 0) cd = tmpd[k - 1];
-                const int cut = cu < cd ? cu : cd;
-                WAVE_SYNC();
-                key = __shfl(key, partner);
-                idx = __shfl(idx, partner);
-                if (last - cut > 16) {
-                    if (lane == 0) { stk[3 * sp] = cut; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth; }
-                    ++sp;
-                } else {
-                    segmask |= 1ull << cut;
-                }
-                last = cut;
-            }
-            if (!ok_depth) break;
-            segmask |= 1ull << first;
-            if (sp == 0) break;
-            --sp;
-            WAVE_SYNC();
-            first = stk[3 * sp]; last = stk[3 * sp + 1]; depth = stk[3 * sp + 2];
-            WAVE_SYNC();
-        }
-    } else {
-        segmask = 1ull;
-    }
-    if (!ok_depth) return false;
-    // final insertion sort == stable sort of every marked segment: my rank inside my segment
-    const int l2 = lane < n ? lane : 0;
-    const uint64_t below = segmask & (lt | (1ull << l2));
-    const int s0 = 63 - __builtin_clzll(below | 1ull);
-    const uint64_t above = (l2 == 63) ? 0ull : (segmask >> (l2 + 1));
-    const int e0 = above ? (l2 + 1 + __builtin_ctzll(above)) : n;
-    int cnt = 0;
-    for (int q = 0; q < 16; ++q) {
-        const int p = s0 + q;
-        const double kq = __shfl(key, p < 64 ? p : 63);
-        const bool in = p < e0 && p != lane;
-        cnt += (in && (less(kq, key) || (!less(key, kq) && p < lane))) ? 1 : 0;
-    }
-    *pos = s0 + cnt;
-    return true;
-}
-
-// The same for groups of BC lanes (BC = 32: two candidates per wave sort side by side).  `n` and `want`
-// are uniform inside a group; the groups run the introsort loop as one predicated state machine (a group
-// that has nothing left idles through the others' partitions).  Scratch: 2*(BC+2)+12 ints per group.
-// Returns (per group) false when the depth limit was hit.
-template <bool DESC, int BC>
-__device__ __forceinline__ bool group_sort(double& key, int& idx, const int n, const bool want, const int lane, int32_t* tmp_wave, int* pos) {
-    auto less = [](double x, double y) { return DESC ? (x > y) : (x < y); };
-    constexpr int TU = BC + 2;
-    const int gl = lane & (BC - 1), gbase = lane & ~(BC - 1);
-    int32_t* tmpu = tmp_wave + (lane / BC) * (2 * TU + 12);
-    int32_t* tmpd = tmpu + TU;
-    int32_t* stk = tmpd + TU;
-    const uint64_t gmask = (BC == 64) ? ~0ull : (0xFFFFFFFFull << gbase);
-    const uint64_t lt = lanemask_lt(lane) & gmask;
-    const uint64_t gt = ((lane == 63) ? 0ull : (~0ull << (lane + 1))) & gmask;
-    uint64_t segmask = 0ull;   // group-relative positions where a <=16-element segment starts
-    bool fail = false;
-    int first = 0, last = want ? n : 0, sp = 0;
-    int depth = n > 1 ? 2 * (31 - __clz(n)) : 0;
-    bool done = !(want && n > 16);
-    if (done) segmask = 1ull;
-    while (true) {
-        if (!done && last - first <= 16) {   // this segment is left to the final insertion sort
-            segmask |= 1ull << first;
-            if (sp == 0) done = true;
-            else { --sp; first = stk[3 * sp]; last = stk[3 * sp + 1]; depth = stk[3 * sp + 2]; }   // pushed segments are > 16 long
-        }
-        if (!done && depth == 0) { fail = true; done = true; }
-        if (__ballot(!done) == 0ull) break;
-        const bool act = !done;
-        depth -= act ? 1 : 0;
-        // __move_median_to_first(first, first+1, mid, last-1)
-        const int ia = act ? first + 1 : 0, ib = act ? first + (last - first) / 2 : 0, ic = act ? last - 1 : 0, fi = act ? first : 0;
-        const double ka = __shfl(key, gbase + ia), kb = __shfl(key, gbase + ib), kc = __shfl(key, gbase + ic);
-        int pick;
-        if (less(ka, kb)) {
-            if (less(kb, kc)) pick = ib;
-            else if (less(ka, kc)) pick = ic;
-            else pick = ia;
-        } else if (less(ka, kc)) pick = ia;
-        else if (less(kb, kc)) pick = ic;
-        else pick = ib;
-        {
-            const double kf = __shfl(key, gbase + fi), kp = __shfl(key, gbase + pick);
-            const int xf = __shfl(idx, gbase + fi), xp = __shfl(idx, gbase + pick);
-            if (act) {
-                if (gl == first) { key = kp; idx = xp; }
-                else if (gl == pick) { key = kf; idx = xf; }
-            }
-        }
-        const double pv = __shfl(key, gbase + fi);
-        const bool inr = act && gl > first && gl < last;
-        const bool su = inr && !less(key, pv);
-        const bool sd = inr && !less(pv, key);
-        const uint64_t mu = __ballot(su) & gmask, md = __ballot(sd) & gmask;
-        const int nu = popc64(mu), nd = popc64(md);
-        const int ru = popc64(mu & lt), rd = popc64(md & gt);
-        if (su) tmpu[ru] = gl;
-        if (sd) tmpd[rd] = gl;
-        if (act && gl == 0) tmpd[nd] = first;   // the pivot itself stops the down-scan
-        WAVE_SYNC();
-        const int tmax = nu < nd ? nu : nd;
-        const bool okp = act && (gl < tmax) && (tmpu[gl] < tmpd[gl]);
-        const int k = popc64(__ballot(okp) & gmask);   // a prefix of the pairs
-        int partner = gl;
-        if (su && ru < k) partner = tmpd[ru];
-        else if (sd && rd < k) partner = tmpu[rd];
-        int cu = 0x7FFFFFFF, cd = 0x7FFFFFFF;
-        if (act && k < nu) cu = tmpu[k];
-        if (act && k > 0) cd = tmpd[k - 1];
-        const int cut = cu < cd ? cu : cd;
-        WAVE_SYNC();
-        key = __shfl(key, gbase + partner);
-        idx = __shfl(idx, gbase + partner);
-        if (act) {
-            if (last - cut > 16) {
-                if (gl == 0) { stk[3 * sp] = cut; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth; }
-                ++sp;
-            } else {
-                segmask |= 1ull << cut;
-            }
-            last = cut;
-        }
-        WAVE_SYNC();
-    }
-    // final insertion sort == stable sort of every marked segment: my rank inside my segment
-    const int l2 = gl < n ? gl : 0;
-    const uint64_t below = segmask & ((2ull << l2) - 1ull);
-    const int s0 = 63 - __builtin_clzll(below | 1ull);
-    const uint64_t above = (l2 == 63) ? 0ull : (segmask >> (l2 + 1));
-    const int e0 = above ? (l2 + 1 + __builtin_ctzll(above)) : n;
-    int cnt = 0;
-    for (int q = 0; q < 16; ++q) {
-        const int p = s0 + q;
-        const double kq = __shfl(key, gbase + (p < BC ? p : BC - 1));
-        const bool in = p < e0 && p != gl;
-        cnt += (in && (less(kq, key) || (!less(key, kq) && p < gl))) ? 1 : 0;
-    }
-    *pos = s0 + cnt;
-    return !fail;
-}
-
-// wave_sort64 out of line for the round loop of the 64-slot kernels: the sort's registers are then not part of the round's pressure
-struct WS64 { double key; int idx; int pos; int ok; };
-template <bool DESC>
-__device__ __noinline__ WS64 wave_sort64_call(double key, int idx, const int n, const int lane, int32_t* tmp) {
-    ASSUME_LDS(tmp);
-    int pos = lane;
-    const bool ok = wave_sort64<DESC>(key, idx, n, lane, tmp, &pos);
-    WS64 r; r.key = key; r.idx = idx; r.pos = pos; r.ok = ok ? 1 : 0;
-    return r;
-}
-
-struct SRecLessKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key < y.key; } };
-struct SRecGreaterKey { __device__ bool operator()(const SRec& x, const SRec& y) const { return x.key > y.key; } };
 
 
 template <int EC>
