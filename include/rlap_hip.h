@@ -182,7 +182,8 @@ int rlap_rng_uniforms(rlap_handle h, int64_t count, double* d_out);
  * (array a = d_keys[d_offs[a] .. d_offs[a+1]), each at most 512 long).  d_perm_out[d_offs[a]+i] = index of the
  * element that ends at position i; compared with libstdc++'s std::sort by tests/test_gpu_parity.py.
  * desc bit 0 = descending; bit 1 = arrays of at most 64 elements use the register-resident variant of the batch kernel;
- * bit 2 = the half-wave variant (arrays of at most 32 elements, two per wave; longer ones are left untouched). */
+ * bit 2 = the half-wave variant (arrays of at most 32 elements, two per wave; longer ones are left untouched);
+ * bit 5 = the long-column sort of the dataflow elimination (rlap_flow.hip; any length up to 65000), bit 6 with it = records in global memory. */
 int rlap_debug_wave_sort(rlap_handle h, const double* d_keys, const int32_t* d_offs, int32_t narr, int32_t desc, int32_t* d_perm_out);
 
 /* Host-side synthetic input (bench/tests): Barabasi-Albert graph as a symmetric,

@@ -300,6 +300,7 @@ int call_sizes(const rlap_handle h, int64_t Eeff, int64_t N, int64_t G, int64_t 
     z->flow = flow;
     z->flow_Q = nelim_total + G;
     z->flow_scr = flow ? (int64_t)(h->flow_scr_factor * (double)std::max<int64_t>(Eeff / 16, 1 << 17)) : 0;
+    if (flow && h->dbg_scr >= 0) z->flow_scr = std::max<int64_t>(h->dbg_scr, 16);   // (test hook: a tiny first size, so that the retry runs)
     if (z->flow_scr >= ((int64_t)1 << 31) - 64) z->flow_scr = ((int64_t)1 << 31) - 64;
     return sort_tmp_bytes(Eeff, N, G, S, flow, &z->sort_tmp);
 }
@@ -563,13 +564,16 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         FlowParams FP;
         FP.vgraph = W.vgraph.as<int32_t>(); FP.gd = W.gd_d.as<GraphDesc>(); FP.in_flags = flags; FP.in_acc = acc;
         FP.scr = W.f_scr.as<char>(); FP.scr_entries = (int32_t)z.flow_scr;
-        FP.spin_limit = 1 << 24; FP.jitter = h->jitter; FP.poison = h->poison;
-        if (const char* e = std::getenv("RLAP_FLOW_SPIN")) FP.spin_limit = std::atoi(e);
+        FP.spin_limit = 4000; FP.jitter = h->jitter; FP.poison = h->poison;
+        FP.prof = ES.prof;
+        if (const char* e = std::getenv("RLAP_FLOW_STALL_MS")) FP.spin_limit = std::max(1, std::atoi(e));
         HIPCHK(hipMemsetAsync(W.f_ctrl.p, 0, 64 * 4, s));
         launch_flow_setup(s, A, FA, FP, W.slot_col.as<int32_t>(), nnz_p, (int32_t)N, Eeff);
-        unsigned grid = 4u * (unsigned)h->n_cu;
+        bool many = G >= 16;
+        if (const char* e = std::getenv("RLAP_FLOW_SHAPE")) many = e[0] == '2';   // diagnostic override: 1 = large block, 2 = small blocks
+        unsigned grid = (many ? 8u : 2u) * (unsigned)h->n_cu;
         if (const char* e = std::getenv("RLAP_FLOW_WAVES")) grid = (unsigned)std::max(1, std::atoi(e));
-        launch_flow_eliminate(c.o_n, grid, s, A, FA, FP);
+        launch_flow_eliminate(many, grid, s, A, FA, FP);
         launch_flow_finish(s, A, FA, W.gd_d.as<GraphDesc>(), (int32_t)N, (int32_t)G);
     } else
     launch_eliminate_batch(c.o_v, c.o_n, (unsigned)G, h->n_cu, s, A, W.gd_d.as<GraphDesc>(), ES, W.batch_pos.as<int32_t>(), flags, acc, wide);
@@ -647,7 +651,15 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     const CallResults& R = *reinterpret_cast<const CallResults*>(h->h_results);
     const int64_t* out_ptr_h = reinterpret_cast<const int64_t*>(reinterpret_cast<const CallResults*>(h->h_results) + 1);
 
-    if (ES.prof) {
+    if (ES.prof && flow) {
+        long long pr[40];
+        HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
+        const char* names[11] = {"claim + wait for pend == 0", "gather", "sort by id (+ tag order)", "merge + publish", "o_n order", "cumsum + recurrence", "look-back wait", "sample", "commit (claims, chunks, stores)", "drain", "decrements"};
+        std::fprintf(stderr, "[rlap flow profile] positions=%lld mean live=%.1f mean extent=%.1f; sums over all waves, us per position\n", pr[16], pr[16] ? (double)pr[17] / pr[16] : 0.0, pr[16] ? (double)pr[18] / pr[16] : 0.0);
+        for (int k = 0; k < 11; ++k) std::fprintf(stderr, "  %-34s %10.3f ms total  %8.2f us/pos\n", names[k], pr[k] / 1e5, pr[16] ? pr[k] / 100.0 / (double)pr[16] : 0.0);
+        std::fprintf(stderr, "  long columns: %lld (mean live %.0f; %lld beyond 900, %lld beyond 1888)\n", pr[36], pr[36] ? (double)pr[37] / pr[36] : 0.0, pr[38], pr[39]);
+        for (int k = 1; k < 11; ++k) std::fprintf(stderr, "    %-32s %10.3f ms total  %8.2f us/col\n", names[k], pr[20 + k] / 1e5, pr[36] ? pr[20 + k] / 100.0 / (double)pr[36] : 0.0);
+    } else if (ES.prof) {
         long long pr[40];
         HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
         const char* names[20] = {"P0 select", "P1 permute + closing barrier", "P1b multi-edge cut + P2 offsets", "P3 sample", "P4 replay", "single path", "P5b slots + shared targets", "move order", "pushes", "P1 meta + loads + dependence", "P5a cursors + pool", "P5c rewire stores", "P1 id rank", "P1 (sync)", "P1 o_n order (sorts)", "P1 write pass", "P1 (sync)", "P1 o_n rank", "empty (cost of one stamp)", "P3b dependent candidates (patch)"};
@@ -715,7 +727,7 @@ int run_call(rlap_handle h, const Call& c) {
         else if (kind == 3) { if (h->dbg_rng >= 0) h->dbg_rng = -1; else h->rng_min = std::max<int64_t>(2 * h->rng_len, 1 << 16); }
         else if (kind == 4) { if (h->dbg_scr >= 0) h->dbg_scr = -1; h->scr_budget = std::max<int64_t>(h->scr_budget, need + 8); }
         else if (kind == 5) h->force_sort = true;
-        else if (kind == 6) h->flow_scr_factor *= 4;
+        else if (kind == 6) { if (h->dbg_scr >= 0) h->dbg_scr = -1; else h->flow_scr_factor *= 4; }
         else if (kind == 7) h->flow_off_once = true;
     }
     h->force_sort = false; h->flow_off_once = false;
@@ -971,6 +983,17 @@ int rlap_rng_uniforms(rlap_handle h, int64_t count, double* d_out) {
 int rlap_debug_wave_sort(rlap_handle h, const double* d_keys, const int32_t* d_offs, int32_t narr, int32_t desc, int32_t* d_perm_out) {
     if (!h || narr < 0) return RLAP_E_BAD_ARG;
     if (narr == 0) return RLAP_OK;
+    if (desc & 32) {   // the dataflow kernel's long-column sort (rlap_flow.hip)
+        int32_t total = 0;
+        HIPCHK(hipMemcpy(&total, d_offs + narr, 4, hipMemcpyDeviceToHost));
+        DevBuf scr;
+        ENSURE(scr, 32 * (size_t)std::max(total, 1) + 64 * (size_t)narr + 256);
+        launch_debug_flow_sort(h->stream, d_keys, d_offs, narr, desc, d_perm_out, scr.as<char>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        scr.release();
+        return RLAP_OK;
+    }
     hipLaunchKernelGGL(k_debug_wave_sort, dim3((unsigned)std::min<int32_t>(narr, 2048)), dim3(64), 0, h->stream, d_keys, d_offs, narr, desc, d_perm_out);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));

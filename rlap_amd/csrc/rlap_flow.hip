@@ -57,8 +57,11 @@ __device__ __forceinline__ void ag_st_slot_val(Slot* p, double val) { ag_st64(re
 
 
 // ---------------------------------------------------------------------------
-// working storage of one column: LDS arrays (short columns) or pointers into the bump-allocated scratch (long ones)
+// working storage of one column: LDS arrays (short columns), or arrays in the bump-allocated scratch with the sort's records,
+// stop lists and tables in the wave's LDS while they fit (long ones)
 // ---------------------------------------------------------------------------
+// long columns: sort records, stop lists and tables in the wave's LDS while they fit (false: everything in global scratch)
+constexpr bool FLOW_BIG_IN_LDS = true;
 template <int EC>
 struct FlowLds {
     static constexpr bool SMALL = true;
@@ -73,63 +76,105 @@ struct FlowLds {
     uint16_t ulist[EC + 2], dlist[EC + 2];
     uint32_t segmark[(EC + 31) / 32 + 1];
     int32_t stk[3 * 48];
-    __device__ double* cum() { return reinterpret_cast<double*>(rec); }
-    __device__ double* newv() { return reinterpret_cast<double*>(rec) + EC; }
+    int32_t tmp[160];                              // register sort's scratch in the long-column form
+    __device__ __forceinline__ double* cum() { return reinterpret_cast<double*>(rec); }
+    __device__ __forceinline__ double* newv() { return reinterpret_cast<double*>(rec) + EC; }
+    __device__ __forceinline__ SRec& R(int i) { return rec[i]; }
 };
-struct FlowGlob {
+// the same LDS block seen by a long column: only what the sorts touch (and afterwards the cumulative weights / new weights)
+constexpr int FLOW_LVL_BIG = 1024;   // long columns up to this many keys take the level-synchronous sort (16 elements per lane)
+template <int EC>
+struct FlowSortLds {
+    static constexpr size_t AVAIL = offsetof(FlowLds<EC>, stk);
+    static constexpr int LVL = (AVAIL >= (size_t)FLOW_LVL_BIG * 26 + 4096) ? FLOW_LVL_BIG : 0;
+    static constexpr int BIGL = (int)((AVAIL - (size_t)LVL * 6 - 64) / 21) & ~7;   // records + two 16-bit lists + marks per entry
+    SRec rec[BIGL];
+    uint16_t ulist[BIGL + 2], dlist[BIGL + 2];
+    uint32_t segmark[BIGL / 32 + 2];
+    uint32_t tab[LVL > 0 ? LVL : 1];
+    uint16_t tab2[LVL > 0 ? LVL : 2];
+};
+template <int EC>
+struct FlowBig {
     static constexpr bool SMALL = false;
-    SRec* rec;
+    FlowSortLds<EC>* S;      // derived from the kernel's __shared__ block (the compiler sees LDS addresses)
+    int32_t* stk; int32_t* tmp;
+    bool lds;                // sort records in LDS (else in the scratch: grec, gulist, gdlist, gsegmark)
+    SRec* grec; uint16_t *gulist, *gdlist; uint32_t* gsegmark;
     double *a_val, *b_val, *skey, *cum_, *newv_;
     int32_t *a_nbr, *a_twin, *a_tag, *b_nbr, *b_twin, *b_dup, *b_pos, *f_dup, *f_pos, *ksel;
-    uint16_t *ulist, *dlist;
-    uint32_t* segmark;
-    int32_t* stk;
-    __device__ double* cum() { return cum_; }
-    __device__ double* newv() { return newv_; }
+    __device__ __forceinline__ double* cum() { return cum_; }
+    __device__ __forceinline__ double* newv() { return newv_; }
+    __device__ __forceinline__ SRec R(int i) const { return lds ? S->rec[i] : grec[i]; }
 };
-// long columns: sort records and stop lists through generic pointers into the wave's LDS (0: everything in global scratch)
-constexpr bool FLOW_BIG_IN_LDS = false;
 static_assert(FLOW_SCR_BYTES >= 16 + 5 * 8 + 10 * 4 + 2 * 2 + 1 && FLOW_SCR_BYTES % 8 == 0, "records, five doubles, ten ints, two 16-bit lists and the segment marks per entry");
 
-// std::sort order of the staged keys B.skey[0..cnt) into B.rec[] = {key, source index} (rlap_wave_sort.h)
-template <bool GREATER, class BUF>
-__device__ __forceinline__ void flow_sort(BUF& B, int cnt, int lane) {
+// std::sort order of the staged keys B.skey[0..cnt) into the records {key, source index} (rlap_wave_sort.h)
+template <bool GREATER, int EC>
+__device__ __forceinline__ void flow_sort(FlowLds<EC>& B, int cnt, int lane) {
     typedef typename std::conditional<GREATER, SRecGreaterKey, SRecLessKey>::type Cmp;
-    if constexpr (BUF::SMALL) {
-        if (cnt <= 64) {
-            double key = lane < cnt ? B.skey[lane] : 0.0;
-            int idx = lane, pos = lane;
-            const bool ok = wave_sort64<GREATER>(key, idx, cnt, lane, B.f_dup, &pos);
-            if (ok) {
-                if (lane < cnt) { B.rec[pos].key = key; B.rec[pos].idx = idx; }
-                WAVE_SYNC();
-                return;
-            }
+    if (cnt <= 64) {
+        double key = lane < cnt ? B.skey[lane] : 0.0;
+        int idx = lane, pos = lane;
+        const bool ok = wave_sort64<GREATER>(key, idx, cnt, lane, B.f_dup, &pos);
+        if (ok) {
+            if (lane < cnt) { B.rec[pos].key = key; B.rec[pos].idx = idx; }
+            WAVE_SYNC();
+            return;
         }
+    }
+    WAVE_SYNC();
+    for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; }
+    WAVE_SYNC();
+    bool ok;
+    constexpr int REGMAX = (EC + 63) / 64;
+    uint32_t* tab = reinterpret_cast<uint32_t*>(B.ksel);
+    uint16_t* tab2 = reinterpret_cast<uint16_t*>(B.f_dup);
+    if (cnt <= 128) ok = wave_lvl_sort<SRec, Cmp, 2>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
+    else if (REGMAX <= 4 || cnt <= 256) ok = wave_lvl_sort<SRec, Cmp, (REGMAX < 4 ? REGMAX : 4)>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
+    else if (REGMAX <= 8 || cnt <= 512) ok = wave_lvl_sort<SRec, Cmp, (REGMAX < 8 ? REGMAX : 8)>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
+    else ok = wave_lvl_sort<SRec, Cmp, REGMAX>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
+    if (!ok) {   // depth limit: std::sort heap-sorts there; start over with the form that follows it
         WAVE_SYNC();
         for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; }
         WAVE_SYNC();
-        bool ok;
-        constexpr int REGMAX = (BUF::CAP + 63) / 64;
-        if (cnt <= 128) ok = wave_lvl_sort<SRec, Cmp, 2>(B.rec, cnt, Cmp(), B.ulist, B.dlist, reinterpret_cast<uint32_t*>(B.ksel), reinterpret_cast<uint16_t*>(B.f_dup), lane);
-        else if (cnt <= 256) ok = wave_lvl_sort<SRec, Cmp, 4>(B.rec, cnt, Cmp(), B.ulist, B.dlist, reinterpret_cast<uint32_t*>(B.ksel), reinterpret_cast<uint16_t*>(B.f_dup), lane);
-        else ok = wave_lvl_sort<SRec, Cmp, REGMAX>(B.rec, cnt, Cmp(), B.ulist, B.dlist, reinterpret_cast<uint32_t*>(B.ksel), reinterpret_cast<uint16_t*>(B.f_dup), lane);
-        if (!ok) {   // depth limit: std::sort heap-sorts there; start over with the form that follows it
-            WAVE_SYNC();
-            for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; }
-            WAVE_SYNC();
-            const WaveSortPtrs WP = {B.ulist, B.dlist, B.segmark, B.stk};
-            wave_std_sort<SRec, Cmp, REGMAX>(B.rec, cnt, Cmp(), WP, lane);
+        const WaveSortPtrs WP = {B.ulist, B.dlist, B.segmark, B.stk};
+        wave_std_sort<SRec, Cmp, 0>(B.rec, cnt, Cmp(), WP, lane);
+    }
+    WAVE_SYNC();
+}
+template <bool GREATER, int EC>
+__device__ __forceinline__ void flow_sort(FlowBig<EC>& B, int cnt, int lane) {
+    typedef typename std::conditional<GREATER, SRecGreaterKey, SRecLessKey>::type Cmp;
+    if (B.lds) {
+        FlowSortLds<EC>& S = *B.S;
+        for (int i = lane; i < cnt; i += 64) { S.rec[i].key = B.skey[i]; S.rec[i].idx = i; }
+        WAVE_SYNC();
+        bool ok = false;
+        if constexpr (FlowSortLds<EC>::LVL > 0) {
+            if (cnt <= FlowSortLds<EC>::LVL) {
+                ok = wave_lvl_sort<SRec, Cmp, FlowSortLds<EC>::LVL / 64>(S.rec, cnt, Cmp(), S.ulist, S.dlist, S.tab, S.tab2, lane);
+                if (!ok) { WAVE_SYNC(); for (int i = lane; i < cnt; i += 64) { S.rec[i].key = B.skey[i]; S.rec[i].idx = i; } WAVE_SYNC(); }
+            }
+        }
+        if (!ok) {
+            const WaveSortPtrs WP = {S.ulist, S.dlist, S.segmark, B.stk};
+            if constexpr (FlowSortLds<EC>::LVL > 0) {
+                // beyond the level-synchronous form's reach: partitions on top, that form for every segment it can take
+                if (cnt > FlowSortLds<EC>::LVL) ok = wave_std_sort_hyb<SRec, Cmp, FlowSortLds<EC>::LVL / 64>(S.rec, cnt, Cmp(), WP, S.tab, S.tab2, lane);
+                if (!ok && cnt > FlowSortLds<EC>::LVL) { WAVE_SYNC(); for (int i = lane; i < cnt; i += 64) { S.rec[i].key = B.skey[i]; S.rec[i].idx = i; } WAVE_SYNC(); }
+            }
+            if (!ok) wave_std_sort<SRec, Cmp, 0>(S.rec, cnt, Cmp(), WP, lane);
         }
         WAVE_SYNC();
     } else {
-        for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; B.rec[i].aux = 0; }
+        for (int i = lane; i < cnt; i += 64) { B.grec[i].key = B.skey[i]; B.grec[i].idx = i; B.grec[i].aux = 0; }
         WAVE_SYNC();
         if (cnt <= 65000) {
-            const WaveSortPtrs WP = {B.ulist, B.dlist, B.segmark, B.stk};
-            wave_std_sort<SRec, Cmp, 0>(B.rec, cnt, Cmp(), WP, lane);
+            const WaveSortPtrs WP = {B.gulist, B.gdlist, B.gsegmark, B.stk};
+            wave_std_sort<SRec, Cmp, 0>(B.grec, cnt, Cmp(), WP, lane);
         } else {
-            if (lane == 0) gs_std_sort<SRec>(B.rec, cnt, Cmp());   // beyond the 16-bit stop lists: one lane
+            if (lane == 0) gs_std_sort<SRec>(B.grec, cnt, Cmp());   // beyond the 16-bit stop lists: one lane
         }
         WAVE_SYNC();
     }
@@ -137,9 +182,20 @@ __device__ __forceinline__ void flow_sort(BUF& B, int cnt, int lane) {
 
 __device__ __forceinline__ bool flow_abort(const FlowArrays& F) { return ag_ld(&F.ctrl[1]) != 0; }
 __device__ __forceinline__ void flow_fail(const FlowArrays& F, int32_t st) { __hip_atomic_fetch_max(&F.ctrl[1], st, RLX, AGT); }
+// A wait may last as long as the elimination itself (the last position of a clique waits for all the others), so it is not the
+// number of polls that is bounded but the time WITHOUT PROGRESS anywhere: ctrl[4] counts committed positions; a waiter gives up
+// (ST_INTERNAL: never a result) when that counter has stood still for `stall_ticks` of the 100 MHz clock.  Called every 64 polls.
+struct FlowWatch { int32_t seen; long long t0; };
+__device__ __forceinline__ bool flow_stalled(const FlowArrays& F, const FlowParams& P, FlowWatch& w) {
+    const int32_t now_p = ag_ld(&F.ctrl[4]);
+    const long long now_t = wall_clock64();
+    if (now_p != w.seen) { w.seen = now_p; w.t0 = now_t; return false; }
+    return now_t - w.t0 > (long long)P.spin_limit * 100000ll;   // spin_limit: milliseconds
+}
 
 // chunk `c` of column k: its base from the directory, allocated by whoever asks first (others wait for the word)
-__device__ __forceinline__ int32_t flow_chunk_base(const Arrays& A, const FlowArrays& F, int32_t k, int c, int32_t spin_limit) {
+__device__ __forceinline__ int32_t flow_chunk_base(const Arrays& A, const FlowArrays& F, const FlowParams& P, int32_t k, int c) {
+    FlowWatch fw = {-1, 0};
     int32_t* word;
     if (c < FDIR - 1) word = F.cdir + (int64_t)k * FDIR + c;
     else {
@@ -159,10 +215,10 @@ __device__ __forceinline__ int32_t flow_chunk_base(const Arrays& A, const FlowAr
                 ob = base;
             } else ob = seen;
         }
-        for (int sp = 0; ob == FD_BUSY; ++sp) {
+        for (int sp = 1; ob == FD_BUSY; ++sp) {
             __builtin_amdgcn_s_sleep(2);
             ob = ag_ld(ow);
-            if (sp > spin_limit) { flow_fail(F, ST_INTERNAL); return FD_FAIL; }
+            if ((sp & 63) == 0 && flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); return FD_FAIL; }
         }
         if (ob < 0) return FD_FAIL;
         word = reinterpret_cast<int32_t*>(A.e + ob) + (c - (FDIR - 1));
@@ -178,10 +234,10 @@ __device__ __forceinline__ int32_t flow_chunk_base(const Arrays& A, const FlowAr
             b = base;
         } else b = seen;
     }
-    for (int sp = 0; b == FD_BUSY; ++sp) {
+    for (int sp = 1; b == FD_BUSY; ++sp) {
         __builtin_amdgcn_s_sleep(2);
         b = ag_ld(word);
-        if (sp > spin_limit) { flow_fail(F, ST_INTERNAL); return FD_FAIL; }
+        if ((sp & 63) == 0 && flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); return FD_FAIL; }
     }
     return b < 0 ? FD_FAIL : b;
 }
@@ -191,12 +247,14 @@ __device__ __forceinline__ int32_t flow_chunk_base(const Arrays& A, const FlowAr
 
 // One position of the order, from the gathered column to the release of the neighbours.  `ext` slots are read (appended + CSR,
 // dead ones included); the live ones must fit `cap`.  Returns false when the launch is being abandoned.
-template <int ON, class BUF>
-__device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays& F, const FlowParams& P, BUF& B, const int32_t cap,
+template <class BUF>
+__device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, const FlowArrays& F, const FlowParams& P, BUF& B, const int32_t cap,
                                                const int32_t idx, const int32_t v, const int32_t cp0, const int32_t cp1, const int32_t acnt,
                                                const int32_t g, const int32_t vbase, const uint64_t gseed, int32_t* last_draws) {
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
+    long long ft_prev = P.prof ? wall_clock64() : 0;
+#define FSTAMP(k) do { if (P.prof) { const long long _t = wall_clock64(); if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + (BUF::SMALL ? 0 : 20) + (k), (unsigned long long)(_t - ft_prev)); ft_prev = _t; } } while (0)
     // ---- gather (:616-639) in physical order: appended index descending, then the CSR segment descending ----
     int len0 = 0, napp = 0;
     {
@@ -240,6 +298,7 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
     }
     if (len0 > cap) { flow_fail(F, ST_INTERNAL); return false; }
     WAVE_SYNC();
+    FSTAMP(1);
 
     // ---- sort by neighbour id (std::sort semantics, :641-644) ----
     for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
@@ -247,12 +306,12 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
     flow_sort<false>(B, len0, lane);
     {   // equal ids: the list order is part of the result -- appended entries newest first (descending tag), then sort again
         bool dup = false;
-        for (int p = lane + 1; p < len0; p += 64) dup |= (B.rec[p].key == B.rec[p - 1].key);
+        for (int p = lane + 1; p < len0; p += 64) dup |= (B.R(p).key == B.R(p - 1).key);
         if (__ballot(dup) != 0ull && napp > 1) {
             for (int i = lane; i < napp; i += 64) B.skey[i] = -(double)B.a_tag[i];
             WAVE_SYNC();
             flow_sort<false>(B, napp, lane);   // distinct keys
-            for (int i = lane; i < napp; i += 64) { const int s = B.rec[i].idx; B.b_nbr[i] = B.a_nbr[s]; B.b_twin[i] = B.a_twin[s]; B.b_val[i] = B.a_val[s]; }
+            for (int i = lane; i < napp; i += 64) { const int s = B.R(i).idx; B.b_nbr[i] = B.a_nbr[s]; B.b_twin[i] = B.a_twin[s]; B.b_val[i] = B.a_val[s]; }
             WAVE_SYNC();
             for (int i = lane; i < napp; i += 64) { B.a_nbr[i] = B.b_nbr[i]; B.a_twin[i] = B.b_twin[i]; B.a_val[i] = B.b_val[i]; }
             WAVE_SYNC();
@@ -262,21 +321,22 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
         }
     }
 
+    FSTAMP(2);
     // ---- merge multi-edges (:646-659): the first of a run keeps its twin and takes the sum (in sorted order), the others' twins die ----
     int m = 0, nk = 0;
     for (int p0 = 0; p0 < len0; p0 += 64) {
         const int p = p0 + lane;
         const bool act = p < len0;
-        const int src = act ? B.rec[p].idx : 0;
+        const int src = act ? B.R(p).idx : 0;
         const int32_t nb = act ? B.a_nbr[src] : -1;
-        const int32_t nbprev = (act && p > 0) ? B.a_nbr[B.rec[p - 1].idx] : -2;
+        const int32_t nbprev = (act && p > 0) ? B.a_nbr[B.R(p - 1).idx] : -2;
         const bool head = act && nb != nbprev;
         const uint64_t mask = __ballot(head), kmask = __ballot(act && !head);
         if (head) {
             const int x = m + popc64(mask & lt);
             double val = B.a_val[src];
             int d = 0;
-            for (int q = p + 1; q < len0 && B.a_nbr[B.rec[q].idx] == nb; ++q) { val += B.a_val[B.rec[q].idx]; ++d; }
+            for (int q = p + 1; q < len0; ++q) { const int sq = B.R(q).idx; if (B.a_nbr[sq] != nb) break; val += B.a_val[sq]; ++d; }
             B.b_nbr[x] = nb; B.b_twin[x] = B.a_twin[src]; B.b_val[x] = val; B.b_dup[x] = d;
             B.b_pos[x] = A.vr[nb].pqpos;   // (positions never change in a launch: a plain load)
         } else if (act) {
@@ -287,6 +347,7 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
     const int32_t cdraw = m > 1 ? m - 1 : 0;
     if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)cdraw);   // my count: later positions can look past me now
     WAVE_SYNC();
+    FSTAMP(3);
     FLOW_JITTER(1);
 
     // ---- order the neighbours by o_n (:661-673) ----
@@ -297,16 +358,52 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
         for (int i = lane; i < m; i += 64) B.skey[i] = B.b_val[i];
     }
     WAVE_SYNC();
-    flow_sort<ON == ON_DESC>(B, m, lane);
+    if (ON == ON_DESC) flow_sort<true>(B, m, lane); else flow_sort<false>(B, m, lane);
     for (int j = lane; j < m; j += 64) {
-        const int x = B.rec[j].idx;
+        const int x = B.R(j).idx;
         B.a_nbr[j] = B.b_nbr[x]; B.a_val[j] = B.b_val[x]; B.a_twin[j] = B.b_twin[x]; B.f_dup[j] = B.b_dup[x]; B.f_pos[j] = B.b_pos[x];
     }
     WAVE_SYNC();
 
+    FSTAMP(4);
     // ---- cumulative weights and the f / colScale / wdeg recurrence (:728-779): one lane, the operation order is the result ----
     double* cum = B.cum();
     double* newv = B.newv();
+    if constexpr (!BUF::SMALL) {
+        if (B.lds && 2 * m <= 2 * B.S->BIGL) {   // the records are free now: the two serial loops run over LDS
+            double* lc = reinterpret_cast<double*>(B.S->rec);
+            for (int j = lane; j < m; j += 64) lc[B.S->BIGL + j] = B.a_val[j];
+            WAVE_SYNC();
+            if (lane == 0) {
+                double csum = 0;
+                for (int j = 0; j < m; ++j) { csum += lc[B.S->BIGL + j]; lc[j] = csum; }
+                double wdeg = csum, colScale = 1;
+                for (int j = 0; j < m - 1; ++j) {
+                    const double w = lc[B.S->BIGL + j] * colScale;
+                    const double f = w / wdeg;
+                    const double omf = 1 - f;
+                    lc[B.S->BIGL + j] = f * omf * wdeg;
+                    colScale = colScale * omf;
+                    wdeg = wdeg * omf * omf;
+                }
+            }
+            WAVE_SYNC();
+            for (int j = lane; j < m; j += 64) { cum[j] = lc[j]; newv[j] = lc[B.S->BIGL + j]; }
+            WAVE_SYNC();
+        } else if (lane == 0) {
+            double csum = 0;
+            for (int j = 0; j < m; ++j) { csum += B.a_val[j]; cum[j] = csum; }
+            double wdeg = csum, colScale = 1;
+            for (int j = 0; j < m - 1; ++j) {
+                const double w = B.a_val[j] * colScale;
+                const double f = w / wdeg;
+                const double omf = 1 - f;
+                newv[j] = f * omf * wdeg;
+                colScale = colScale * omf;
+                wdeg = wdeg * omf * omf;
+            }
+        }
+    } else
     if (lane == 0) {
         double csum = 0;
         for (int j0 = 0; j0 < m; j0 += 8) {
@@ -336,12 +433,14 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
     }
     WAVE_SYNC();
 
+    FSTAMP(5);
     // ---- uniform offset: decoupled look-back over the published counts (the stream is consumed in order, :729) ----
     long long D = 0;
     {
         long long sum = 0;
         int32_t hi = idx - 1;   // highest position not yet added
         int spins = 0;
+        FlowWatch fw = {-1, 0};
         while (true) {
             const int32_t q = hi - lane;
             unsigned long long wv = LB_VALID | LB_PREFIX;   // below the array: never reached (a sentinel stops the walk)
@@ -359,14 +458,17 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
                 continue;
             }
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63) == 0 && flow_abort(F)) return false;
-            if (spins > P.spin_limit) { flow_fail(F, ST_INTERNAL); return false; }
+            if ((++spins & 63) == 0) {
+                if (flow_abort(F)) return false;
+                if (flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); return false; }
+            }
         }
         D = sum;
     }
     if (D + cdraw > A.rng_len) { flow_fail(F, ST_RNG_OVERFLOW); return false; }
     if (lane == 0) ag_st64(F.lb + idx, LB_VALID | LB_PREFIX | (unsigned long long)(D + cdraw));
     *last_draws = (int32_t)(D + cdraw);
+    FSTAMP(6);
     FLOW_JITTER(2);
 
     // ---- sample k for every position but the last (:747-756) ----
@@ -379,6 +481,7 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
     }
     WAVE_SYNC();
 
+    FSTAMP(7);
     // ---- commit (:766-776): the new entry is appended to column k, the twin rewritten in place; live pairs are counted at the end that
     //      comes later; then my last neighbour's entry and the merged duplicates' twins die (:791-792, :655) ----
     bool failed = false;
@@ -396,7 +499,7 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
             c = chunk_of(ai);
         }
         FLOW_JITTER(3 + (lane & 3));
-        if (act) base = flow_chunk_base(A, F, k, c, P.spin_limit);
+        if (act) base = flow_chunk_base(A, F, P, k, c);
         if (act && base >= 0) {
             const int32_t s_n = base + 1 + (ai - chunk_start(c));
             ag_st_slot(A.e + s_n, nw, a, s_r);
@@ -410,11 +513,18 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
     }
     if (lane == 0 && m >= 1) ag_st_slot_val(A.e + B.a_twin[m - 1], 0.0);
     for (int i = lane; i < nk; i += 64) ag_st_slot_val(A.e + B.a_tag[i], 0.0);
+    FSTAMP(8);
     DRAIN_STORES();   // every store and increment of this wave has arrived before a neighbour is released
+    FSTAMP(9);
     FLOW_JITTER(8);
     for (int j = lane; j < m; j += 64) {
         if (B.f_pos[j] != FPOS_NONE) ag_add(&A.vr[B.a_nbr[j]].key, -(1 + B.f_dup[j]));
     }
+    if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[4], 1, RLX, AGT);   // progress (flow_stalled)
+    FSTAMP(10);
+    if (P.prof && lane == 0 && !BUF::SMALL) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 36, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 37, (unsigned long long)len0); if (len0 > 900) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 38, 1ull); if (len0 > 1888) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 39, 1ull); }
+    if (P.prof && lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 16, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 17, (unsigned long long)len0); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 18, (unsigned long long)(cp1 - cp0 + acnt)); }
+#undef FSTAMP
     (void)g;
     return __ballot(failed) == 0ull;
 }
@@ -423,10 +533,12 @@ __device__ __forceinline__ bool flow_eliminate(const Arrays& A, const FlowArrays
 // The persistent kernel: one wave per workgroup; grid = as many as are wanted in flight (they need not all be resident: a
 // workgroup that starts late claims later positions, and what a position waits for is always held by a running wave).
 // ---------------------------------------------------------------------------
-template <int ON, int EC>
-__global__ __launch_bounds__(64) void k_eliminate_flow(Arrays A, FlowArrays F, FlowParams P) {
+template <int EC, int MINW>
+__global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArrays F, FlowParams P) {
     __shared__ FlowLds<EC> L;
+    static_assert(sizeof(FlowSortLds<EC>) <= offsetof(FlowLds<EC>, stk), "the long-column sort does not fit the wave's LDS");
     const int lane = lane_id();
+    const int ON = A.o_n;
     if (P.poison >= 0) {
         uint32_t* const w = reinterpret_cast<uint32_t*>(&L);
         const uint32_t pat = 0x01010101u * (uint32_t)(P.poison & 0xFF);
@@ -441,6 +553,7 @@ __global__ __launch_bounds__(64) void k_eliminate_flow(Arrays A, FlowArrays F, F
         if (bad) { if (lane == 0 && blockIdx.x == 0) flow_fail(F, bad); return; }
     }
     while (true) {
+        long long mt0 = P.prof ? wall_clock64() : 0;
         int32_t idx = 0;
         if (lane == 0) idx = ag_add(&F.ctrl[0], 1);
         idx = __builtin_amdgcn_readfirstlane(idx);
@@ -452,17 +565,21 @@ __global__ __launch_bounds__(64) void k_eliminate_flow(Arrays A, FlowArrays F, F
         {
             int spins = 0;
             int32_t pend = 1;
+            FlowWatch fw = {-1, 0};
             while (true) {
                 if (lane == 0) pend = ag_ld(&A.vr[v].key);
                 pend = __builtin_amdgcn_readfirstlane(pend);
                 if (pend == 0) break;
                 __builtin_amdgcn_s_sleep(2);
                 ++spins;
-                if ((spins & 63) == 0 && flow_abort(F)) { pend = -1; break; }
-                if (spins > P.spin_limit) { flow_fail(F, ST_INTERNAL); pend = -1; break; }
+                if ((spins & 63) == 0) {
+                    if (flow_abort(F)) { pend = -1; break; }
+                    if (flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); pend = -1; break; }
+                }
             }
             if (pend != 0) break;
         }
+        if (P.prof && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 0, (unsigned long long)(wall_clock64() - mt0));
         const int32_t g = F.qg[idx];
         const int32_t vbase = P.gd[g].vbase;
         const uint64_t gseed = A.shuffle_seed + (uint64_t)g;
@@ -474,44 +591,31 @@ __global__ __launch_bounds__(64) void k_eliminate_flow(Arrays A, FlowArrays F, F
         int32_t draws = 0;
         bool ok;
         if (ext <= EC) {
-            ok = flow_eliminate<ON>(A, F, P, L, EC, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+            ok = flow_eliminate(ON, A, F, P, L, EC, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
         } else {
-            // long column: working storage from the bump allocator; the sort records and stop lists stay in LDS while they fit
+            // long column: the arrays come from the bump allocator; the sort's records, stop lists and tables stay in LDS while they fit
             int32_t b0 = 0;
             const int32_t want = ext + 8;
             if (lane == 0) b0 = ag_add(&F.ctrl[2], want);
             b0 = __builtin_amdgcn_readfirstlane(b0);
             if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); break; }
             char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
-            FlowGlob Gb;
+            FlowBig<EC> Gb;
             const int64_t n8 = want;
             double* d = reinterpret_cast<double*>(base);
             Gb.a_val = d; Gb.b_val = d + n8; Gb.skey = d + 2 * n8; Gb.cum_ = d + 3 * n8; Gb.newv_ = d + 4 * n8;
             int32_t* ip = reinterpret_cast<int32_t*>(d + 5 * n8);
             Gb.a_nbr = ip; Gb.a_twin = ip + n8; Gb.a_tag = ip + 2 * n8; Gb.b_nbr = ip + 3 * n8; Gb.b_twin = ip + 4 * n8; Gb.b_dup = ip + 5 * n8;
             Gb.b_pos = ip + 6 * n8; Gb.f_dup = ip + 7 * n8; Gb.f_pos = ip + 8 * n8; Gb.ksel = ip + 9 * n8;
-            constexpr size_t LDS_FREE = offsetof(FlowLds<EC>, stk);                 // everything in front of the segment stack
-            constexpr int BIGL = (int)((LDS_FREE - 64) / 21) & ~7;                  // records + two 16-bit lists + marks per entry
-            constexpr size_t OFF_U = (size_t)BIGL * 16, OFF_D = OFF_U + 2 * (size_t)(BIGL + 2), OFF_M = (OFF_D + 2 * (size_t)(BIGL + 2) + 3) & ~(size_t)3;
-            static_assert(OFF_M + 4 * (size_t)(BIGL / 32 + 2) <= LDS_FREE, "the long-column sort does not fit the wave's LDS");
-            if (FLOW_BIG_IN_LDS && ext <= BIGL) {
-                char* lb = reinterpret_cast<char*>(&L);
-                Gb.rec = reinterpret_cast<SRec*>(lb);
-                Gb.ulist = reinterpret_cast<uint16_t*>(lb + OFF_U);
-                Gb.dlist = reinterpret_cast<uint16_t*>(lb + OFF_D);
-                Gb.segmark = reinterpret_cast<uint32_t*>(lb + OFF_M);
-                Gb.stk = L.stk;
-            } else {
-                // everything in global scratch: records behind the ints, lists behind the records (want + 8 entries each)
-                char* q = reinterpret_cast<char*>(ip + 10 * n8);
-                // 16-byte alignment of the records: 5 * 8 * n8 + 10 * 4 * n8 = 80 * n8 bytes in front
-                Gb.rec = reinterpret_cast<SRec*>(q);
-                Gb.ulist = reinterpret_cast<uint16_t*>(q + 16 * n8);
-                Gb.dlist = Gb.ulist + n8;
-                Gb.segmark = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(Gb.dlist + n8));
-                Gb.stk = L.stk;
-            }
-            ok = flow_eliminate<ON>(A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+            char* q = reinterpret_cast<char*>(ip + 10 * n8);   // 80 * n8 bytes in front: 8-byte aligned
+            Gb.grec = reinterpret_cast<SRec*>(q);
+            Gb.gulist = reinterpret_cast<uint16_t*>(q + 16 * n8);
+            Gb.gdlist = Gb.gulist + n8;
+            Gb.gsegmark = reinterpret_cast<uint32_t*>(Gb.gdlist + n8);
+            Gb.S = reinterpret_cast<FlowSortLds<EC>*>(&L);
+            Gb.stk = L.stk; Gb.tmp = L.tmp;
+            Gb.lds = FLOW_BIG_IN_LDS && ext <= FlowSortLds<EC>::BIGL;
+            ok = flow_eliminate(ON, A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
             if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[3], 1, RLX, AGT);
         }
         if (!ok) break;
@@ -629,11 +733,31 @@ __global__ void k_flow_ro_store(Arrays A, FlowArrays F, const int32_t* __restric
     for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < M; r += gridDim.x * blockDim.x) { A.e[home[r]] = tmp[r]; F.atag[home[r]] = (int32_t)(uint32_t)(sorted_keys[r] & 0xFFFFFFFFull); }
 }
 
-template <int EC>
-static void launch_flow_t(int o_n, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
-    if (o_n == ON_ASC) hipLaunchKernelGGL((k_eliminate_flow<ON_ASC, EC>), dim3(grid), dim3(64), 0, stream, A, F, P);
-    else if (o_n == ON_DESC) hipLaunchKernelGGL((k_eliminate_flow<ON_DESC, EC>), dim3(grid), dim3(64), 0, stream, A, F, P);
-    else hipLaunchKernelGGL((k_eliminate_flow<ON_RANDOM, EC>), dim3(grid), dim3(64), 0, stream, A, F, P);
+// test hook (rlap_debug_wave_sort, desc bit 5): the long-column sort of the dataflow kernel -- one workgroup sorts one array of
+// doubles, records in LDS (level-synchronous / hybrid / partition forms by length) or, with desc bit 6 or beyond the LDS block, in
+// global scratch; returns the permutation.  Compared with std::sort itself by tests/test_gpu_flow.py.
+__global__ __launch_bounds__(64) void k_debug_flow_sort(const double* __restrict__ keys, const int32_t* __restrict__ offs, int32_t narr, int32_t desc,
+                                                        int32_t* __restrict__ perm_out, char* __restrict__ scr) {
+    __shared__ FlowLds<FLOW_EC> L;
+    const int lane = lane_id();
+    for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
+        const int32_t o = offs[arr], n = offs[arr + 1] - o;
+        FlowBig<FLOW_EC> B;
+        B.S = reinterpret_cast<FlowSortLds<FLOW_EC>*>(&L); B.stk = L.stk; B.tmp = L.tmp;
+        B.lds = !(desc & 64) && n <= FlowSortLds<FLOW_EC>::BIGL;
+        B.skey = const_cast<double*>(keys) + o;
+        char* base = scr + 32 * (int64_t)o + 64 * (int64_t)arr;
+        B.grec = reinterpret_cast<SRec*>(base);
+        B.gulist = reinterpret_cast<uint16_t*>(base + 16 * (int64_t)n);
+        B.gdlist = B.gulist + (n + 2);
+        B.gsegmark = reinterpret_cast<uint32_t*>(base + 20 * (int64_t)n + 8);
+        if (desc & 1) flow_sort<true>(B, n, lane); else flow_sort<false>(B, n, lane);
+        for (int q = lane; q < n; q += 64) perm_out[o + q] = B.R(q).idx;
+        WAVE_SYNC();
+    }
+}
+void launch_debug_flow_sort(hipStream_t s, const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out, char* scr) {
+    hipLaunchKernelGGL(k_debug_flow_sort, dim3((unsigned)std::min<int32_t>(narr, 512)), dim3(64), 0, s, keys, offs, narr, desc, perm_out, scr);
 }
 
 void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p,
@@ -648,8 +772,11 @@ void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, cons
     }
 }
 
-void launch_flow_eliminate(int o_n, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
-    launch_flow_t<FLOW_EC>(o_n, grid, stream, A, F, P);
+// two shapes: one wave with a large LDS block, two workgroups per CU (a single large graph: what bounds the run is how fast a long
+// column is dealt with); or a small block, eight per CU (a batch of small graphs: what bounds the run is how many positions are in flight)
+void launch_flow_eliminate(bool many, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
+    if (many) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_SMALL, 2>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    else hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
 }
 
 void launch_flow_finish(hipStream_t s, const Arrays& A, const FlowArrays& F, GraphDesc* gd, int32_t N, int32_t G) {

@@ -112,7 +112,8 @@ void launch_eq_tables(hipStream_t stream, uint8_t* out);
 void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t stream, const Arrays& A, GraphDesc* gd, const ElimScratch& S,
                             int32_t* batch_pos, const int32_t* flags, const double* acc, bool wide);
 // ---- dataflow elimination for o_v = random (rlap_flow.hip) ----
-constexpr int FLOW_EC = 448;              // column extent a wave handles in its own LDS (four one-wave workgroups per CU)
+constexpr int FLOW_EC = 896;              // column extent a wave handles in its own LDS (two one-wave workgroups per CU)
+constexpr int FLOW_EC_SMALL = 192;        // ... in the shape for batches of small graphs (eight per CU)
 constexpr int FLOW_SCR_BYTES = 104;       // working storage per entry of a longer column (bump-allocated, rlap_flow.hip)
 struct FlowParams {
     const int32_t* vgraph;
@@ -121,12 +122,14 @@ struct FlowParams {
     const double* in_acc;
     char* scr;               // long columns: bump-allocated working storage (FLOW_SCR_BYTES per entry)
     int32_t scr_entries;
-    int32_t spin_limit;      // polls (with s_sleep) a wait may take before the launch gives up with ST_INTERNAL
+    int32_t spin_limit;      // milliseconds without a committed position anywhere after which a waiting wave gives up (ST_INTERNAL)
     int32_t jitter;          // debug: waves sleep at the phase boundaries (schedule perturbation)
     int32_t poison;          // debug: LDS starts as this byte
+    long long* prof;         // diagnostic (RLAP_PHASE_PROFILE=1): per-phase sums of the 100 MHz clock over all waves, nullptr in production
 };
 void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int64_t Eeff);
-void launch_flow_eliminate(int o_n, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P);
+void launch_flow_eliminate(bool many, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P);
+void launch_debug_flow_sort(hipStream_t s, const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out, char* scr);
 void launch_flow_finish(hipStream_t s, const Arrays& A, const FlowArrays& F, GraphDesc* gd, int32_t N, int32_t G);
 void launch_flow_ro_count(hipStream_t s, const Arrays& A, const FlowArrays& F, const uint32_t* order, int32_t S, int32_t* cnt);
 void launch_flow_ro_emit(hipStream_t s, const Arrays& A, const FlowArrays& F, const uint32_t* order, int32_t S, const int32_t* off, uint64_t* keys, uint32_t* vals,

@@ -255,7 +255,7 @@ __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int
 // partly partitioned and the caller starts over with wave_std_sort on the original order.
 // ---------------------------------------------------------------------------
 template <class T, class Less, int REG>
-__device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* ulist, uint16_t* dlist, uint32_t* tab, uint16_t* tab2, int lane) {
+__device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* ulist, uint16_t* dlist, uint32_t* tab, uint16_t* tab2, int lane, int depth_in = -1) {
     if (n < 2) return true;
     const uint64_t lt = lanemask_lt(lane);
     const uint64_t le = lt | (1ull << lane);
@@ -267,6 +267,7 @@ __device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* uli
     int depth = 0;
     for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth;
     depth *= 2;
+    if (depth_in >= 0) depth = depth_in;   // a segment of a larger array (wave_std_sort_hyb): the introsort loop's remaining depth limit
     int first[REG], last[REG];
     while (true) {
         // segment of every element: nearest start at or below / above its position
@@ -396,6 +397,146 @@ __device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* uli
     WAVE_SYNC();
 #pragma unroll
     for (int t = 0; t < REG; ++t) if (rr[t] >= 0) a[rr[t]] = vv[t];
+    WAVE_SYNC();
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Long arrays in LDS: wave_std_sort's partition loop while a segment is longer than 64*LREG elements, the level-synchronous form
+// (with the loop's remaining depth limit) for every segment at or below that -- a partition of a short segment costs the whole
+// wave as much as one of a long segment, and most partitions of a long array are short.  Same permutation as wave_std_sort.
+// Returns false when a level-synchronous part meets the depth limit (the array is then partly partitioned: the caller starts
+// over from the original order with wave_std_sort, which follows std::sort into its heap sort).
+// ---------------------------------------------------------------------------
+template <class T, class Less, int LREG>
+__device__ bool wave_std_sort_hyb(T* a, int n, Less less, const WaveSortPtrs W_, uint32_t* tab, uint16_t* tab2, int lane) {
+    struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
+    if (n < 2) return true;
+    const uint64_t lt = lanemask_lt(lane);
+    for (int q = lane; q < (n + 31) / 32 + 1; q += 64) W.segmark[q] = 0u;
+    WAVE_SYNC();
+    if (n <= 16) {
+        if (lane == 0) gs_insertion_sort<T>(a, n, less);
+        WAVE_SYNC();
+        return true;
+    }
+    int depth0 = 0;
+    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+    depth0 *= 2;
+    int sp = 0;
+    if (lane == 0) { W.stk[0] = 0; W.stk[1] = n; W.stk[2] = depth0; }
+    sp = 1;
+    WAVE_SYNC();
+    while (sp > 0) {
+        --sp;
+        int first = W.stk[3 * sp], last = W.stk[3 * sp + 1], depth = W.stk[3 * sp + 2];
+        bool whole = false;   // [first, last) was finished by the level-synchronous form
+        while (last - first > 16) {
+            if (last - first <= 64 * LREG) {
+                if (!wave_lvl_sort<T, Less, LREG>(a + first, last - first, less, W.ulist + first, W.dlist + first, tab, tab2, lane, depth)) return false;
+                // sorted through: any split of it is a valid set of final segments -- one mark every 16 elements
+                for (int q = first + 16 * lane; q < last; q += 16 * 64) atomicOr(&W.segmark[q >> 5], 1u << (q & 31));
+                WAVE_SYNC();
+                whole = true;
+                break;
+            }
+            if (depth == 0) {
+                if (lane == 0) gs_heap_sort<T>(a, first, last, less);
+                WAVE_SYNC();
+                break;
+            }
+            --depth;
+            if (lane == 0) {
+                int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                int pick;
+                if (less(a[ia], a[ib])) {
+                    if (less(a[ib], a[ic])) pick = ib;
+                    else if (less(a[ia], a[ic])) pick = ic;
+                    else pick = ia;
+                } else if (less(a[ia], a[ic])) pick = ia;
+                else if (less(a[ib], a[ic])) pick = ic;
+                else pick = ib;
+                T t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            WAVE_SYNC();
+            const T pv = a[first];
+            int nu = 0, nd = 0;
+            for (int p0 = first + 1; p0 < last; p0 += 64) {
+                int p = p0 + lane;
+                bool stop = (p < last) && !less(a[p], pv);
+                uint64_t mk = __ballot(stop);
+                if (stop) W.ulist[nu + popc64(mk & lt)] = (uint16_t)p;
+                nu += popc64(mk);
+            }
+            for (int p0 = last - 1; p0 > first; p0 -= 64) {
+                int p = p0 - lane;
+                bool stop = (p > first) && !less(pv, a[p]);
+                uint64_t mk = __ballot(stop);
+                if (stop) W.dlist[nd + popc64(mk & lt)] = (uint16_t)p;
+                nd += popc64(mk);
+            }
+            if (lane == 0) W.dlist[nd] = (uint16_t)first;
+            WAVE_SYNC();
+            int k = 0;
+            {
+                const int tmax = nu < nd ? nu : nd;
+                bool open = true;
+                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
+                    int t = t0 + lane;
+                    bool ok = (t < tmax) && (W.ulist[t] < W.dlist[t]);
+                    uint64_t mk = __ballot(ok);
+                    uint64_t inv = ~mk;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    k += run;
+                    open = (run == 64);
+                }
+            }
+            T xu, xd;
+            for (int t0 = 0; t0 < k; t0 += 64) {
+                int t = t0 + lane;
+                if (t < k) { xu = a[W.ulist[t]]; xd = a[W.dlist[t]]; }
+                WAVE_SYNC();
+                if (t < k) { a[W.ulist[t]] = xd; a[W.dlist[t]] = xu; }
+                WAVE_SYNC();
+            }
+            int cut;
+            {
+                int cu = (k < nu) ? (int)W.ulist[k] : 0x7FFFFFFF;
+                int cd = (k > 0) ? (int)W.dlist[k - 1] : 0x7FFFFFFF;
+                cut = cu < cd ? cu : cd;
+            }
+            WAVE_SYNC();
+            if (last - cut > 16) {
+                if (lane == 0) { W.stk[3 * sp] = cut; W.stk[3 * sp + 1] = last; W.stk[3 * sp + 2] = depth; }
+                ++sp;
+            } else if (lane == 0) {
+                atomicOr(&W.segmark[cut >> 5], 1u << (cut & 31));
+            }
+            WAVE_SYNC();
+            last = cut;
+        }
+        if (!whole && lane == 0) atomicOr(&W.segmark[first >> 5], 1u << (first & 31));
+        WAVE_SYNC();
+    }
+    // final insertion sort: lane l takes the segments that start in the 32-position words l, l+64, ...
+    for (int w0 = lane; w0 * 32 < n; w0 += 64) {
+        uint32_t bits = W.segmark[w0];
+        while (bits) {
+            const int s0 = w0 * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            int e0 = n;
+            if (bits) e0 = w0 * 32 + __builtin_ctz(bits);
+            else {
+                for (int w1 = w0 + 1; w1 * 32 < n; ++w1) { uint32_t bb = W.segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } }
+            }
+            for (int i = s0 + 1; i < e0; ++i) {
+                T v = a[i];
+                int j = i - 1;
+                while (j >= s0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
+                a[j + 1] = v;
+            }
+        }
+    }
     WAVE_SYNC();
     return true;
 }

@@ -1,0 +1,203 @@
+"""GPU parity of the multi-CU ("dataflow") elimination for o_v = "random" (rlap_amd/csrc/rlap_flow.hip, RLAP_FLOW=1) against the CPU
+oracle: row order, indices and weights bit for bit; its long-column sorts against libstdc++'s std::sort itself; schedule jitter and
+poisoned memory; the same rows as the round kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import ba_graph, clique, grid2d, introsort_killer, path, star, sym_weights, symmetrize
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from rlap_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture()
+def flow_env():
+    old = {k: os.environ.get(k) for k in ("RLAP_FLOW", "RLAP_FLOW_SHAPE", "RLAP_FLOW_WAVES")}
+    os.environ["RLAP_FLOW"] = "1"
+    yield os.environ
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def call(ops, ei, w, n, t, o_n, perm, seed=3):
+    out = ops.approximate_cholesky(torch.from_numpy(np.ascontiguousarray(ei)).cuda(), None if w is None else torch.from_numpy(w).cuda(), n, t,
+                                   "random", o_n, perm=torch.from_numpy(np.asarray(perm, dtype=np.int64)), seed=seed)
+    return out.numpy()
+
+
+def check(ops, ei, w, n, t, o_n, perm, what):
+    a = oracle.approximate_cholesky(ei, w, n, t, "random", o_n, perm=perm, shuffle_seed=3)
+    b = call(ops, ei, w, n, t, o_n, perm)
+    assert a.shape == b.shape, f"{what}: rows {b.shape} vs {a.shape}"
+    assert np.array_equal(a, b), f"{what}: {int((a != b).any(axis=1).sum())} rows differ"
+
+
+def test_flow_long_column_sorts_match_libstdcxx(ops):
+    """The sort forms a long column goes through (records in LDS: level-synchronous up to 1024 keys, partitions on top of it beyond;
+    records in global memory) against std::sort itself: ties, runs, killers."""
+    rng = np.random.RandomState(1)
+    arrays = []
+    for trial in range(160):
+        n = int(rng.choice([1, 2, 16, 17, 64, 65, 200, 897, 1000, 1024, 1025, 1100, 1500, 2047, 2300, 3000, 3500, 3600, 5000, 9000]))
+        kind = trial % 6
+        if kind == 0:
+            k = np.ones(n)
+        elif kind == 1:
+            k = rng.randint(0, 3, size=n).astype(float)
+        elif kind == 2:
+            k = rng.rand(n)
+        elif kind == 3:
+            k = np.sort(rng.randint(0, n // 4 + 1, size=n)).astype(float)
+        elif kind == 4:
+            k = np.sort(rng.randint(0, n // 4 + 1, size=n))[::-1].astype(float)
+        else:
+            k = np.concatenate([np.ones(n // 2), rng.rand(n - n // 2)])[rng.permutation(n)]
+        arrays.append(k)
+    for n in (200, 900, 1024, 2000, 3000):
+        k, hit = introsort_killer(n)
+        assert hit
+        arrays += [k, -k, np.concatenate([k, k[: n // 3]])]
+    offs = np.zeros(len(arrays) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(a) for a in arrays])
+    keys = torch.from_numpy(np.concatenate(arrays)).cuda()
+    offs_t = torch.from_numpy(offs).cuda()
+    lib, h = ops._handle(torch.device("cuda", 0))
+    for desc in (32, 33, 96, 97):   # bit 5: the dataflow kernel's sort; bit 0: descending; bit 6: records in global memory
+        out = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device="cuda")
+        assert lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr()) == 0
+        got = out.cpu().numpy()
+        for a_i, k in enumerate(arrays):
+            exp = oracle.stdsort_perm(k, bool(desc & 1))
+            assert np.array_equal(got[offs[a_i]:offs[a_i + 1]], exp), (a_i, len(k), desc)
+
+
+GRAPHS = [("K4", clique(4), 4), ("K6", clique(6), 6), ("P9", path(9), 9), ("star7", star(7), 7), ("K40", clique(40), 40),
+          ("grid5x6", grid2d(5, 6), 30), ("BA100_50", ba_graph(100, 50, 0), 100), ("BA500_3", ba_graph(500, 3, 1), 500),
+          ("BA3000_10", ba_graph(3000, 10, 2), 3000), ("BA400_40", ba_graph(400, 40, 5), 400)]
+
+
+@pytest.mark.parametrize("shape", ["1", "2"])
+@pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
+def test_flow_matches_oracle(ops, flow_env, o_n, shape):
+    """All graph families x weights x num_remove, both workgroup shapes (large LDS block / small blocks)."""
+    flow_env["RLAP_FLOW_SHAPE"] = shape
+    rng = np.random.RandomState(7)
+    for nm, ei, n in GRAPHS:
+        perm = rng.permutation(n)
+        for wts in (None, sym_weights(ei, n, 5)):
+            for t in sorted({0, 1, n // 2, n - 1, n + 5}):
+                check(ops, ei, wts, n, t, o_n, perm, (nm, o_n, t, wts is not None))
+
+
+def test_flow_long_columns_and_hubs(ops, flow_env):
+    """Columns beyond the wave's LDS block (dense graph), beyond the inline chunk directory (hubs taking thousands of appended
+    entries from concurrent eliminations), a star whose centre goes first."""
+    rng = np.random.RandomState(5)
+    ei = ba_graph(1200, 200, 4)
+    perm = rng.permutation(1200)
+    for t in (600, 1199):
+        check(ops, ei, None, 1200, t, "asc", perm, ("BA1200_200", t))
+    check(ops, ei, sym_weights(ei, 1200, 5), 1200, 900, "desc", perm, "BA1200_200 w")
+    n = 3000
+    a0 = np.concatenate([np.zeros(n - 2, dtype=np.int64), np.ones(n - 2, dtype=np.int64), np.arange(2, n - 1)])
+    b0 = np.concatenate([np.arange(2, n), np.arange(2, n), np.arange(3, n)])
+    ei = symmetrize(a0, b0, n)
+    for hubs_last in (True, False):
+        perm = np.concatenate([[0, 1], 2 + rng.permutation(n - 2)]) if hubs_last else np.concatenate([2 + rng.permutation(n - 2), [1, 0]])
+        for t in (n - 3, n - 1, n // 2):
+            check(ops, ei, None, n, t, "asc", perm, ("hubs", hubs_last, t))
+    ei = star(5000)
+    perm = np.concatenate([1 + rng.permutation(4999), [0]])   # the centre is popped first: one 4999-entry column
+    check(ops, ei, None, 5000, 2500, "asc", perm, "star5000")
+    check(ops, ei, sym_weights(ei, 5000, 2), 5000, 2500, "desc", perm, "star5000 w")
+
+
+def test_flow_equals_round_kernel_on_a_medium_graph(ops, flow_env):
+    from rlap_amd import graphs
+    n = 120000
+    ei = graphs.barabasi_albert(n, 10, 5).cuda()
+    perm = torch.from_numpy(np.random.RandomState(3).permutation(n))
+    flow_env["RLAP_FLOW"] = "0"
+    a = ops.approximate_cholesky(ei, None, n, n // 2, "random", "asc", perm=perm, return_device="same")
+    assert ops.last_stats["n_rounds"] > 0
+    flow_env["RLAP_FLOW"] = "1"
+    b = ops.approximate_cholesky(ei, None, n, n // 2, "random", "asc", perm=perm, return_device="same")
+    assert ops.last_stats["n_rounds"] == 0, "the dataflow kernel did not run"
+    assert a.shape == b.shape and torch.equal(a, b)
+    for waves in ("7", "300"):   # any number of waves in flight gives the same rows
+        flow_env["RLAP_FLOW_WAVES"] = waves
+        c = ops.approximate_cholesky(ei, None, n, n // 2, "random", "asc", perm=perm, return_device="same")
+        assert torch.equal(a, c), waves
+    flow_env.pop("RLAP_FLOW_WAVES", None)
+    # one wave: the sequential order itself (a smaller graph: one wave is slow)
+    n2 = 4000
+    ei2 = ba_graph(n2, 6, 9)
+    perm2 = np.random.RandomState(4).permutation(n2)
+    flow_env["RLAP_FLOW_WAVES"] = "1"
+    check(ops, ei2, None, n2, n2 // 2, "asc", perm2, "one wave")
+
+
+def test_flow_batched_equals_single_calls(ops, flow_env):
+    """A batch: every graph has its own uniform stream (look-back stops at the graph's sentinel) and its own seed."""
+    from rlap_amd import graphs
+    rng = np.random.RandomState(2)
+    sizes = [300, 1, 0, 777, 64, 2048, 5]
+    eis = [graphs.barabasi_albert(s, 4, 100 + i) if s > 8 else torch.from_numpy(clique(s) if s > 1 else np.zeros((2, 0), dtype=np.int64)) for i, s in enumerate(sizes)]
+    big, node_ptr = graphs.batch_disjoint(eis, sizes)
+    perm = np.concatenate([rng.permutation(s) for s in sizes]).astype(np.int64)
+    ts = [s // 2 for s in sizes]
+    for o_n in ("asc", "random"):
+        sc, rp = ops.approximate_cholesky_batched(big.cuda(), None, node_ptr, ts, "random", o_n, perm=torch.from_numpy(perm), seed=5)
+        sc = sc.cpu().numpy()
+        off = 0
+        for g, s in enumerate(sizes):
+            a = oracle.approximate_cholesky(eis[g].numpy(), None, s, ts[g], "random", o_n, perm=perm[off:off + s], shuffle_seed=5 + g)
+            b = sc[rp[g]:rp[g + 1]].copy()
+            b[:, :2] -= off
+            assert a.shape == b.shape and np.array_equal(a, b), (g, s, o_n)
+            off += s
+
+
+def test_flow_under_jitter_and_poison(ops, flow_env):
+    """Schedule perturbation (waves sleep at the phase boundaries and between their claims and stores) and poisoned arena / LDS:
+    the rows do not move."""
+    n = 6000
+    ei = ba_graph(n, 8, 11)
+    perm = np.random.RandomState(6).permutation(n)
+    a = oracle.approximate_cholesky(ei, None, n, n // 2, "random", "asc", perm=perm, shuffle_seed=3)
+    try:
+        for jit, poison in ((3, -1), (9, 170), (0, 255), (5, 0)):
+            ops.debug_set_jitter(jit)
+            ops.debug_set_poison(poison)
+            for shape in ("1", "2"):
+                flow_env["RLAP_FLOW_SHAPE"] = shape
+                b = call(ops, ei, None, n, n // 2, "asc", perm)
+                assert a.shape == b.shape and np.array_equal(a, b), (jit, poison, shape)
+    finally:
+        ops.debug_set_jitter(0)
+        ops.debug_set_poison(-1)
+
+
+def test_flow_growth_retries(ops, flow_env):
+    """Tiny pool / uniform table / long-column scratch: the call repeats itself with more and returns the same rows."""
+    n = 3000
+    ei = ba_graph(n, 10, 2)
+    perm = np.random.RandomState(8).permutation(n)
+    a = oracle.approximate_cholesky(ei, None, n, n - 1, "random", "asc", perm=perm, shuffle_seed=3)
+    ops.debug_set_limits(pool_factor=0.05, log_factor=0.05, rng_len=1000, scratch_entries=16)
+    b = call(ops, ei, None, n, n - 1, "asc", perm)
+    assert ops.last_stats["n_retries"] >= 1
+    assert a.shape == b.shape and np.array_equal(a, b)
