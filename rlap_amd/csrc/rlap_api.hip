@@ -179,10 +179,14 @@ int sort_tmp_bytes(int64_t Eeff, int64_t N, int64_t G, int64_t S, bool flow, siz
 }
 
 // o_v = random runs the dataflow kernel (rlap_flow.hip) unless RLAP_FLOW=0 asks for the round kernel
-inline bool flow_wanted(const rlap_handle h, int o_v) {
+// (default: single graphs and pairs -- a batch of many small graphs is bound by the positions in flight, where one workgroup per graph
+// with a round's loads all in flight together does better: 1024 x BA(4096,8) 20 ms against 61 ms; RLAP_FLOW=1 forces it for any batch)
+inline bool flow_wanted(const rlap_handle h, int o_v, int64_t G) {
     if (o_v != OV_RANDOM || h->flow_off_once) return false;
     const char* e = std::getenv("RLAP_FLOW");
-    return e ? (e[0] != '0') : false;
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    return G <= 2;
 }
 
 constexpr int64_t SORT_SKIP_MIN = 1 << 21;   // directed entries from which the order of the input is looked at before sorting it
@@ -272,7 +276,7 @@ size_t carve(Carver& C, const Sizes& z, WS& W) {
     W.biglist.p = C.take<int32_t>(8 * (S + 1));
     W.hugelists.p = C.take<uint16_t>((int64_t)NHUGE * 2 * (HUGECAP + 2));
     if (z.flow) {
-        W.f_ctrl.p = C.take<int32_t>(64);
+        W.f_ctrl.p = C.take<int32_t>(FC_WORDS);
         W.f_cdir.p = C.take<int32_t>(N * FDIR);
         W.f_atag.p = C.take<int32_t>(z.slot_cap);
         W.f_lb.p = C.take<unsigned long long>(z.flow_Q); W.f_qv.p = C.take<int32_t>(z.flow_Q); W.f_qg.p = C.take<int32_t>(z.flow_Q);
@@ -362,7 +366,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     const int64_t S = surv_base[G];
     st.n_eliminated = nelim_total;
     Sizes z;
-    const bool flow = flow_wanted(h, c.o_v);
+    const bool flow = flow_wanted(h, c.o_v, G);
     { int rc = call_sizes(h, Eeff, N, G, bucket_total, S, c.o_v == OV_RANDOM && !c.d_perm, flow, nelim_total, &z); if (rc) return rc; }
     const int64_t slot_cap = z.slot_cap, log_total = z.log_total, scr_total = z.scr_total, scr_budget = z.scr_budget;
     const size_t res_bytes = z.res_bytes;
@@ -567,8 +571,16 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         FP.spin_limit = 4000; FP.jitter = h->jitter; FP.poison = h->poison;
         FP.prof = ES.prof;
         if (const char* e = std::getenv("RLAP_FLOW_STALL_MS")) FP.spin_limit = std::max(1, std::atoi(e));
-        HIPCHK(hipMemsetAsync(W.f_ctrl.p, 0, 64 * 4, s));
-        launch_flow_setup(s, A, FA, FP, W.slot_col.as<int32_t>(), nnz_p, (int32_t)N, Eeff);
+        HIPCHK(hipMemsetAsync(W.f_ctrl.p, 0, FC_WORDS * 4, s));
+        FA.qorder = nullptr; FA.Qclaim = FA.Q;
+        const bool interleave = G > 1 && nelim_total > 0;   // a batch: claims run over the graphs' positions interleaved, so that every graph has waves
+        launch_flow_setup(s, A, FA, FP, W.slot_col.as<int32_t>(), nnz_p, (int32_t)N, Eeff, interleave ? W.skey0.as<uint64_t>() : nullptr,
+                          interleave ? W.sval0.as<uint32_t>() : nullptr, (int)gbits);
+        if (interleave) {
+            int rc = sort_pairs(h, ST, W.skey0.as<uint64_t>(), W.skey1.as<uint64_t>(), W.sval0.as<uint32_t>(), W.sval1.as<uint32_t>(), nelim_total, 0, std::min(64u, 32u + gbits));
+            if (rc) return rc;
+            FA.qorder = W.sval1.as<uint32_t>(); FA.Qclaim = (int32_t)nelim_total;
+        }
         bool many = G >= 16;
         if (const char* e = std::getenv("RLAP_FLOW_SHAPE")) many = e[0] == '2';   // diagnostic override: 1 = large block, 2 = small blocks
         unsigned grid = (many ? 8u : 2u) * (unsigned)h->n_cu;
@@ -657,7 +669,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         const char* names[11] = {"claim + wait for pend == 0", "gather", "sort by id (+ tag order)", "merge + publish", "o_n order", "cumsum + recurrence", "look-back wait", "sample", "commit (claims, chunks, stores)", "drain", "decrements"};
         std::fprintf(stderr, "[rlap flow profile] positions=%lld mean live=%.1f mean extent=%.1f; sums over all waves, us per position\n", pr[16], pr[16] ? (double)pr[17] / pr[16] : 0.0, pr[16] ? (double)pr[18] / pr[16] : 0.0);
         for (int k = 0; k < 11; ++k) std::fprintf(stderr, "  %-34s %10.3f ms total  %8.2f us/pos\n", names[k], pr[k] / 1e5, pr[16] ? pr[k] / 100.0 / (double)pr[16] : 0.0);
-        std::fprintf(stderr, "  long columns: %lld (mean live %.0f; %lld beyond 900, %lld beyond 1888)\n", pr[36], pr[36] ? (double)pr[37] / pr[36] : 0.0, pr[38], pr[39]);
+        std::fprintf(stderr, "  long columns: %lld (mean live %.0f, max %lld; %lld beyond 900, %lld beyond 1888, %lld beyond 3320 taking %.3f of %.3f ms)\n", pr[36], pr[36] ? (double)pr[37] / pr[36] : 0.0, pr[35], pr[38], pr[39], pr[32], pr[33] / 1e5, pr[34] / 1e5);
         for (int k = 1; k < 11; ++k) std::fprintf(stderr, "    %-32s %10.3f ms total  %8.2f us/col\n", names[k], pr[20 + k] / 1e5, pr[36] ? pr[20 + k] / 100.0 / (double)pr[36] : 0.0);
     } else if (ES.prof) {
         long long pr[40];
@@ -787,7 +799,7 @@ static int ws_query(const rlap_handle h, int64_t E, int64_t n_total, int64_t G, 
     const rlap_handle hh = h ? h : &defaults;
     Sizes z;
     // bounds that hold for every split of n_total over G graphs and every num_remove: 2n+1 buckets per graph, S <= n_total
-    int rc = call_sizes(hh, Eeff, n_total, G, 2 * n_total + G, n_total, true, flow_wanted(hh, OV_RANDOM), n_total, &z);
+    int rc = call_sizes(hh, Eeff, n_total, G, 2 * n_total + G, n_total, true, flow_wanted(hh, OV_RANDOM, G), n_total, &z);
     if (rc) return rc;
     WS W; Carver dry{nullptr, 0};
     *ws_bytes = carve(dry, z, W);

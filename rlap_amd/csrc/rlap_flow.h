@@ -35,14 +35,19 @@ constexpr int32_t FPOS_NONE = 0x7FFFFFFF;  // VRec::pqpos of a vertex that is no
 // look-back word of a position: bit 63 = count published, bit 62 = the value is the INCLUSIVE prefix (else the position's own count)
 constexpr unsigned long long LB_VALID = 1ull << 63, LB_PREFIX = 1ull << 62, LB_MASK = (1ull << 62) - 1ull;
 
+// control words (index into FlowArrays::ctrl): next claim, abort status, long-column scratch top (entries), long columns met, committed positions
+enum { FC_CLAIM = 0, FC_ABORT = 32, FC_SCR = 64, FC_LONG = 96, FC_PROGRESS = 128, FC_WORDS = 160 };
+
 struct FlowArrays {
     int32_t* cdir;              // [N * FDIR]
     int32_t* atag;              // [slot_cap] uniform index of the draw that created an appended entry
     unsigned long long* lb;     // [Q] look-back words; a graph's positions are preceded by one sentinel (prefix 0)
     const int32_t* qv;          // [Q] vertex of a position, -1 for a sentinel
     const int32_t* qg;          // [Q] graph of a position (sentinels too)
-    int32_t* ctrl;              // [0] next position to claim, [1] abort status, [2] big-column scratch top (entries), [3] spare
+    int32_t* ctrl;              // control words, each on a 128-byte line of its own (FC_*): all waves hammer the first two
     int32_t Q;                  // positions + sentinels
+    const uint32_t* qorder;     // claim order (batches: positions of all graphs interleaved, [Qclaim]); nullptr = 0, 1, 2, ... over lb[]
+    int32_t Qclaim;             // claims to hand out
 };
 
 RLAP_HD int32_t* flow_dir_word(const FlowArrays& F, int32_t v, int c) { return F.cdir + (int64_t)v * FDIR + c; }

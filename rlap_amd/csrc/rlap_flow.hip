@@ -180,14 +180,14 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC>& B, int cnt, int lane) {
     }
 }
 
-__device__ __forceinline__ bool flow_abort(const FlowArrays& F) { return ag_ld(&F.ctrl[1]) != 0; }
-__device__ __forceinline__ void flow_fail(const FlowArrays& F, int32_t st) { __hip_atomic_fetch_max(&F.ctrl[1], st, RLX, AGT); }
+__device__ __forceinline__ bool flow_abort(const FlowArrays& F) { return ag_ld(&F.ctrl[FC_ABORT]) != 0; }
+__device__ __forceinline__ void flow_fail(const FlowArrays& F, int32_t st) { __hip_atomic_fetch_max(&F.ctrl[FC_ABORT], st, RLX, AGT); }
 // A wait may last as long as the elimination itself (the last position of a clique waits for all the others), so it is not the
 // number of polls that is bounded but the time WITHOUT PROGRESS anywhere: ctrl[4] counts committed positions; a waiter gives up
 // (ST_INTERNAL: never a result) when that counter has stood still for `stall_ticks` of the 100 MHz clock.  Called every 64 polls.
 struct FlowWatch { int32_t seen; long long t0; };
 __device__ __forceinline__ bool flow_stalled(const FlowArrays& F, const FlowParams& P, FlowWatch& w) {
-    const int32_t now_p = ag_ld(&F.ctrl[4]);
+    const int32_t now_p = ag_ld(&F.ctrl[FC_PROGRESS]);
     const long long now_t = wall_clock64();
     if (now_p != w.seen) { w.seen = now_p; w.t0 = now_t; return false; }
     return now_t - w.t0 > (long long)P.spin_limit * 100000ll;   // spin_limit: milliseconds
@@ -254,6 +254,7 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
     long long ft_prev = P.prof ? wall_clock64() : 0;
+    const long long ft_begin = ft_prev;
 #define FSTAMP(k) do { if (P.prof) { const long long _t = wall_clock64(); if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + (BUF::SMALL ? 0 : 20) + (k), (unsigned long long)(_t - ft_prev)); ft_prev = _t; } } while (0)
     // ---- gather (:616-639) in physical order: appended index descending, then the CSR segment descending ----
     int len0 = 0, napp = 0;
@@ -520,9 +521,10 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
     for (int j = lane; j < m; j += 64) {
         if (B.f_pos[j] != FPOS_NONE) ag_add(&A.vr[B.a_nbr[j]].key, -(1 + B.f_dup[j]));
     }
-    if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[4], 1, RLX, AGT);   // progress (flow_stalled)
+    if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_PROGRESS], 1, RLX, AGT);   // progress (flow_stalled)
     FSTAMP(10);
-    if (P.prof && lane == 0 && !BUF::SMALL) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 36, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 37, (unsigned long long)len0); if (len0 > 900) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 38, 1ull); if (len0 > 1888) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 39, 1ull); }
+    if (P.prof && lane == 0 && !BUF::SMALL) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 36, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 37, (unsigned long long)len0); if (len0 > 900) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 38, 1ull); if (len0 > 1888) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 39, 1ull);
+        const unsigned long long dt = (unsigned long long)(wall_clock64() - ft_begin); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 34, dt); if (len0 > 3320) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 32, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 33, dt); } atomicMax(reinterpret_cast<unsigned long long*>(P.prof) + 35, (unsigned long long)len0); }
     if (P.prof && lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 16, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 17, (unsigned long long)len0); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 18, (unsigned long long)(cp1 - cp0 + acnt)); }
 #undef FSTAMP
     (void)g;
@@ -555,9 +557,10 @@ __global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArray
     while (true) {
         long long mt0 = P.prof ? wall_clock64() : 0;
         int32_t idx = 0;
-        if (lane == 0) idx = ag_add(&F.ctrl[0], 1);
+        if (lane == 0) idx = ag_add(&F.ctrl[FC_CLAIM], 1);
         idx = __builtin_amdgcn_readfirstlane(idx);
-        if (idx >= F.Q) break;
+        if (idx >= F.Qclaim) break;
+        if (F.qorder) idx = (int32_t)F.qorder[idx];   // batches: the graphs' positions interleaved (any order that keeps each graph's own is valid)
         const int32_t v = F.qv[idx];
         if (v < 0) continue;   // a graph's sentinel
         if (flow_abort(F)) break;
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArray
             // long column: the arrays come from the bump allocator; the sort's records, stop lists and tables stay in LDS while they fit
             int32_t b0 = 0;
             const int32_t want = ext + 8;
-            if (lane == 0) b0 = ag_add(&F.ctrl[2], want);
+            if (lane == 0) b0 = ag_add(&F.ctrl[FC_SCR], want);
             b0 = __builtin_amdgcn_readfirstlane(b0);
             if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); break; }
             char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArray
             Gb.stk = L.stk; Gb.tmp = L.tmp;
             Gb.lds = FLOW_BIG_IN_LDS && ext <= FlowSortLds<EC>::BIGL;
             ok = flow_eliminate(ON, A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
-            if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[3], 1, RLX, AGT);
+            if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_LONG], 1, RLX, AGT);
         }
         if (!ok) break;
         // the last position of a graph files the graph's draw count
@@ -628,7 +631,8 @@ __global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArray
 // setup: positions, queue, sentinels, pending counters
 // ---------------------------------------------------------------------------
 __global__ void k_flow_queue(const int64_t* __restrict__ perm, const int32_t* __restrict__ vgraph, const GraphDesc* __restrict__ gd, int32_t N,
-                             VRec* __restrict__ vr, int32_t* __restrict__ qv, int32_t* __restrict__ qg, unsigned long long* __restrict__ lb) {
+                             VRec* __restrict__ vr, int32_t* __restrict__ qv, int32_t* __restrict__ qg, unsigned long long* __restrict__ lb,
+                             uint64_t* __restrict__ okey, uint32_t* __restrict__ oval, int gbits) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int32_t g = vgraph[i];
@@ -642,6 +646,7 @@ __global__ void k_flow_queue(const int64_t* __restrict__ perm, const int32_t* __
         const int32_t li = D.flow_base + 1 + (int32_t)p;
         qv[li] = v; qg[li] = g; lb[li] = 0ull;
         vr[v].pqpos = li;
+        if (okey) { const int32_t pi = D.flow_base - g + (int32_t)p; okey[pi] = ((uint64_t)p << gbits) | (uint64_t)(uint32_t)g; oval[pi] = (uint32_t)li; }   // claim order: by position, then graph
     }
     if (idx == 0) { qv[D.flow_base] = -1; qg[D.flow_base] = g; lb[D.flow_base] = LB_VALID | LB_PREFIX; }
 }
@@ -672,9 +677,9 @@ __global__ void k_flow_finish(Arrays A, FlowArrays F, GraphDesc* __restrict__ gd
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) flow_finish_vertex(A, F, i);
     if (i < G) {
-        const int32_t st = F.ctrl[1];
+        const int32_t st = F.ctrl[FC_ABORT];
         if (st) gd[i].status = st;
-        gd[i].pad0 = 0; gd[i].pad1 = (i == 0) ? F.ctrl[3] : 0;   // ("rounds" has no meaning here; "singles" = long columns)
+        gd[i].pad0 = 0; gd[i].pad1 = (i == 0) ? F.ctrl[FC_LONG] : 0;   // ("rounds" has no meaning here; "singles" = long columns)
     }
 }
 
@@ -761,11 +766,11 @@ void launch_debug_flow_sort(hipStream_t s, const double* keys, const int32_t* of
 }
 
 void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p,
-                       int32_t N, int64_t Eeff) {
+                       int32_t N, int64_t Eeff, uint64_t* okey, uint32_t* oval, int gbits) {
     const unsigned nb = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(k_flow_qinit, dim3((unsigned)((F.Q + 255) / 256)), dim3(256), 0, s, const_cast<int32_t*>(F.qv), const_cast<int32_t*>(F.qg), F.lb, F.Q);
     hipLaunchKernelGGL(k_flow_vinit, dim3(nb), dim3(256), 0, s, A.vr, F.cdir, N);
-    hipLaunchKernelGGL(k_flow_queue, dim3(nb), dim3(256), 0, s, A.perm, P.vgraph, P.gd, N, A.vr, const_cast<int32_t*>(F.qv), const_cast<int32_t*>(F.qg), F.lb);
+    hipLaunchKernelGGL(k_flow_queue, dim3(nb), dim3(256), 0, s, A.perm, P.vgraph, P.gd, N, A.vr, const_cast<int32_t*>(F.qv), const_cast<int32_t*>(F.qg), F.lb, okey, oval, gbits);
     if (Eeff > 0) {
         const unsigned ne = (unsigned)std::min<int64_t>((Eeff + 255) / 256, 8192);
         hipLaunchKernelGGL(k_flow_pending, dim3(ne), dim3(256), 0, s, A.e, slot_col, nnz_p, A.vr);

@@ -127,7 +127,8 @@ struct FlowParams {
     int32_t poison;          // debug: LDS starts as this byte
     long long* prof;         // diagnostic (RLAP_PHASE_PROFILE=1): per-phase sums of the 100 MHz clock over all waves, nullptr in production
 };
-void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int64_t Eeff);
+void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int64_t Eeff,
+                       uint64_t* okey, uint32_t* oval, int gbits);
 void launch_flow_eliminate(bool many, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P);
 void launch_debug_flow_sort(hipStream_t s, const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out, char* scr);
 void launch_flow_finish(hipStream_t s, const Arrays& A, const FlowArrays& F, GraphDesc* gd, int32_t N, int32_t G);

@@ -558,7 +558,7 @@ extern "C" int mirror_flow_chol(const int64_t* row, const int64_t* col, const do
     if (nelim < 0) nelim = 0;
     // ---- flow state ----
     const int32_t Q = (int32_t)nelim + 1;
-    std::vector<int32_t> cdir((size_t)n * FDIR, FD_EMPTY), atag((size_t)A.slot_cap, -1), qv((size_t)Q, -1), qg((size_t)Q, 0), ctrl(4, 0);
+    std::vector<int32_t> cdir((size_t)n * FDIR, FD_EMPTY), atag((size_t)A.slot_cap, -1), qv((size_t)Q, -1), qg((size_t)Q, 0), ctrl(FC_WORDS, 0);
     std::vector<unsigned long long> lb((size_t)Q, 0ull);
     FlowArrays F;
     F.cdir = cdir.data(); F.atag = atag.data(); F.lb = lb.data(); F.qv = qv.data(); F.qg = qg.data(); F.ctrl = ctrl.data(); F.Q = Q;
@@ -614,8 +614,8 @@ extern "C" int mirror_flow_chol(const int64_t* row, const int64_t* col, const do
     auto step = [&](FWave& X) -> int {
         switch (X.state) {
         case 0: {
-            int32_t idx = ctrl[0]++;
-            while (idx < Q && qv[idx] < 0) idx = ctrl[0]++;   // sentinels
+            int32_t idx = ctrl[FC_CLAIM]++;
+            while (idx < Q && qv[idx] < 0) idx = ctrl[FC_CLAIM]++;   // sentinels
             if (idx >= Q) { X.state = 5; ++ndone; return 0; }
             X.idx = idx; X.v = qv[idx]; X.state = 1;
             return 0;
