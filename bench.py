@@ -42,7 +42,7 @@ def parse_args(argv=None):
     ap.add_argument("--o_n", default="asc")
     ap.add_argument("--weighted", action="store_true", help="SURVEY 8(d) variant: w ~ U(0.5,1.5) per undirected edge, seed 3 (tie-free path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-runs", type=int, default=3, help="c3: full oracle runs the CPU baseline is the median of")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="c3: full oracle runs the CPU baseline is the median of (SURVEY 8(d) says 10; five of the headline workload take about 25 s)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--master-port", type=int, default=29541)
     return ap.parse_args(argv)
@@ -108,7 +108,7 @@ def _usable_cores():
 
 def _kernels_sha():
     h = hashlib.sha256()
-    for f in ("rlap_kernels.hip", "rlap_core.h", "rlap_api.hip", "Makefile"):
+    for f in ("rlap_kernels.hip", "rlap_flow.hip", "rlap_flow.h", "rlap_wave_sort.h", "rlap_core.h", "rlap_api.hip", "Makefile"):
         h.update(open(os.path.join(ROOT, "rlap_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -326,7 +326,9 @@ def main():
             "first_call_ms": first_call_ms,
             "phase_ms": {k: avg(k) for k in ("ms_setup", "ms_elim", "ms_output", "ms_sc_merge", "ms_sc_compact", "ms_total")},
             # dominant kernel by time: the sequential-semantics elimination (latency bound, not bandwidth bound)
-            "roofline": roof("k_eliminate_batch", elim_bytes, ms_elim) if not c5 else roof("k_sc_compact", compact_bytes, ms_compact),
+            # (o_v = random on a single graph: the multi-CU dataflow kernel, rlap_flow.hip -- n_rounds is 0 there)
+            "elimination_kernel": "k_eliminate_flow" if (o_v == "random" and st["n_rounds"] == 0 and n_elim > 0) else "k_eliminate_batch",
+            "roofline": roof("k_eliminate_flow" if (o_v == "random" and st["n_rounds"] == 0 and n_elim > 0) else "k_eliminate_batch", elim_bytes, ms_elim) if not c5 else roof("k_sc_compact", compact_bytes, ms_compact),
             "roofline_k9": roof("k9_output_pass", k9_bytes, ms_output),
             "roofline_sc_merge": roof("k_sc_merge", merge_bytes, ms_merge),
             "roofline_sc_compact": roof("k_sc_compact", compact_bytes, ms_compact),

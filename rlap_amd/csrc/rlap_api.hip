@@ -482,7 +482,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
                            reinterpret_cast<int32_t*>(rowid));
     }
     // (nnz = pos[Eeff]: k_colptr reads it there and files it in the scalar block and as the pool's first free slot)
-    hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, W.slot_col.as<int32_t>(), Eeff > 0 ? W.pos.as<int32_t>() + Eeff : (const int32_t*)nnz_p, (int32_t)N,
+    hipLaunchKernelGGL(k_colptr, dim3(nblk(N + 1, 256)), dim3(256), 0, s, W.slot_col.as<int32_t>(), Eeff > 0 ? W.pos.as<int32_t>() + Eeff : (const int32_t*)&SC->pad, (int32_t)N,   // (no entries: a zeroed word of its own, not the output word -- both are __restrict__)
                        W.colptr.as<int32_t>(), nnz_p, W.pool_top.as<int32_t>());
     if (Eeff > 0) {
         // twins: stable sort of the slots by row id (keys0 is free again: sorted keys in its first half, the slot order T in its second)
@@ -752,6 +752,27 @@ int run_call(rlap_handle h, const Call& c) {
 
 extern "C" {
 
+// the body of rlap_create: any failure leaves a partly built handle that rlap_create hands to rlap_destroy
+static int create_into(rlap_handle h) {
+    for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
+    for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& st : h->side) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // everything a call needs besides its arena and the uniform table is allocated here, once: the equal-key permutation tables
+    // (built on one of the handle's own non-blocking streams -- not the null stream, which would serialise against every blocking
+    // stream of the caller -- and finished before rlap_create returns), the pinned read-back block, the diagnostic profile
+    ENSURE(h->small, 256);
+    ENSURE(h->eqtab, EQTAB_BYTES);
+    launch_eq_tables(h->side[0], h->eqtab.as<uint8_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->side[0]));
+    HIPCHK(hipHostMalloc(&h->h_results, 1 << 17, hipHostMallocDefault));
+    h->h_results_cap = 1 << 17;
+    if (const char* e = std::getenv("RLAP_PHASE_PROFILE")) { if (e[0] == '1') ENSURE(h->prof, 8 * 40); }
+    if (const char* e = std::getenv("RLAP_DEBUG_POISON")) { if (e[0]) h->poison = std::atoi(e) & 0xFF; }
+    if (const char* e = std::getenv("RLAP_DEBUG_JITTER")) { if (e[0]) h->jitter = std::max(0, std::min(64, std::atoi(e))); }
+    return RLAP_OK;
+}
+
 int rlap_create(rlap_handle* out) {
     if (!out) return RLAP_E_BAD_ARG;
     int dev = 0;
@@ -759,21 +780,10 @@ int rlap_create(rlap_handle* out) {
     rlap_handle h = new rlap_handle_s();
     h->device = dev;
     if (hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || h->n_cu <= 0) h->n_cu = 256;
-    for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
-    for (auto& e : h->fork_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto& st : h->side) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    // everything a call needs besides its arena and the uniform table is allocated here, once: the equal-key permutation tables
-    // (built on the null stream, finished before rlap_create returns), the pinned read-back block, the diagnostic profile
-    ENSURE(h->small, 256);
-    ENSURE(h->eqtab, EQTAB_BYTES);
-    launch_eq_tables(nullptr, h->eqtab.as<uint8_t>());
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(nullptr));
-    HIPCHK(hipHostMalloc(&h->h_results, 1 << 17, hipHostMallocDefault));
-    h->h_results_cap = 1 << 17;
-    if (const char* e = std::getenv("RLAP_PHASE_PROFILE")) { if (e[0] == '1') ENSURE(h->prof, 8 * 40); }
-    if (const char* e = std::getenv("RLAP_DEBUG_POISON")) { if (e[0]) h->poison = std::atoi(e) & 0xFF; }
-    if (const char* e = std::getenv("RLAP_DEBUG_JITTER")) { if (e[0]) h->jitter = std::max(0, std::min(64, std::atoi(e))); }
+    for (auto& e : h->ev) e = nullptr;
+    for (auto& e : h->fork_ev) e = nullptr;
+    const int rc = create_into(h);
+    if (rc != RLAP_OK) { (void)rlap_destroy(h); return rc; }
     *out = h;
     return RLAP_OK;
 }
@@ -783,8 +793,8 @@ int rlap_destroy(rlap_handle h) {
     DeviceGuard dg(h->device);
     if (h->h_results) (void)hipHostFree(h->h_results);
     h->own_ws.release(); h->own_rng.release(); h->eqtab.release(); h->prof.release(); h->small.release();
-    for (auto& e : h->ev) (void)hipEventDestroy(e);
-    for (auto& e : h->fork_ev) (void)hipEventDestroy(e);
+    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : h->fork_ev) if (e) (void)hipEventDestroy(e);
     for (auto& st : h->side) if (st) (void)hipStreamDestroy(st);
     delete h;
     return RLAP_OK;

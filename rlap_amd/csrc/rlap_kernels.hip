@@ -1653,8 +1653,9 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     ColBuf Bf = S2.colbuf(G.scr_base);
                     const bool handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase, s_help);
                     if (!handled && lane == 0) {   // (a column the long-column path took has told the helper itself)
-                        serial_eliminate_call(A2, G, S2, v0, done + 1);
+                        // no help wanted: said BEFORE the one-lane elimination, which may last longer than the helper's wait
                         __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        serial_eliminate_call(A2, G, S2, v0, done + 1);
                     }
                 } else {
                     wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr, s_help);
@@ -2340,8 +2341,8 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                         handled = wave_eliminate_big(A2, G, sh.g, Bf, G.scr_cap, v0, cp0, cp1, acnt, abase, s_help);
                     }
                     if (!handled && lane == 0) {
+                        __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (before, not after: see above)
                         serial_eliminate_call(A2, G, S2, v0, done + 1);
-                        __hip_atomic_store(&s_help[0], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 } else {
                     wave_eliminate(A2, G, sh.e, v0, done + 1, cp0, cp1, acnt, abase, (S.prof && g == 0) ? &s_prof[24] : nullptr, s_help);

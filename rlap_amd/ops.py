@@ -112,10 +112,16 @@ def _run(hobj, dev, E: int, n_total: int, G: int, symmetrize: bool, call, st):
     that it wants more (a growth limit was met and the repeated attempt is of a larger size class) grow and call again."""
     lib = hobj.lib
     ws_b, rng_n = ctypes.c_size_t(0), ctypes.c_int64(0)
-    rc = lib.rlap_workspace_query(hobj.ptr, E, n_total, G, 1 if symmetrize else 0, ctypes.byref(ws_b), ctypes.byref(rng_n))
-    if rc != 0:
-        _raise(rc)
-    hobj.fit(dev, ws_b.value, rng_n.value)
+    if n_total is None:
+        # num_nodes is found on the device inside the call: no bound is asked for up front (the only host-known one, 2 * E vertices,
+        # is off by twice the mean degree -- gigabytes at ogbn-arxiv size, and RLAP_E_TOO_LARGE long before the true n is).  The call
+        # itself says what it wants at the true n (RLAP_E_WORKSPACE, below) when the arena at hand is too small.
+        hobj.fit(dev, 4096, 1 << 16)
+    else:
+        rc = lib.rlap_workspace_query(hobj.ptr, E, n_total, G, 1 if symmetrize else 0, ctypes.byref(ws_b), ctypes.byref(rng_n))
+        if rc != 0:
+            _raise(rc)
+        hobj.fit(dev, ws_b.value, rng_n.value)
     retries = 0
     for _ in range(8):
         rc = call()
@@ -287,9 +293,7 @@ def approximate_cholesky_from_edges(
         rows = ctypes.c_int64(0)
         nn = ctypes.c_int64(0)
         st = _lib.Stats()
-        # num_nodes unknown (found on the device inside the call): a graph has no more vertices than endpoints -- an upper bound for the arena
-        n_ub = n if n >= 0 else max(2 * E, 1)
-        rc = _run(hobj, dev, E, n_ub, 1, bool(symmetrize), lambda: lib.rlap_approx_chol_from_edges(
+        rc = _run(hobj, dev, E, n if n >= 0 else None, 1, bool(symmetrize), lambda: lib.rlap_approx_chol_from_edges(
             h, row.data_ptr(), col.data_ptr(), w.data_ptr() if w is not None else None, E, n, t, float(remove_frac),
             1 if symmetrize else 0, O_V[o_v], O_N[o_n], d_perm.data_ptr() if d_perm is not None else None, shuffle_seed,
             out.data_ptr(), out.shape[0], ctypes.byref(rows), ctypes.byref(nn), ctypes.byref(st)), st)

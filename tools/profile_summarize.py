@@ -95,7 +95,7 @@ def pick(prefix):
 
 import hashlib
 _h = hashlib.sha256()
-for _f in ("rlap_kernels.hip", "rlap_core.h", "rlap_api.hip", "Makefile"):
+for _f in ("rlap_kernels.hip", "rlap_flow.hip", "rlap_flow.h", "rlap_wave_sort.h", "rlap_core.h", "rlap_api.hip", "Makefile"):
     _h.update(open(os.path.join(ROOT, "rlap_amd", "csrc", _f), "rb").read())
 traffic = {
     "_kernels_sha": _h.hexdigest()[:16],   # bench.py reports these figures only while the kernel sources are the profiled ones
