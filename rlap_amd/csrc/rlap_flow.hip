@@ -180,6 +180,35 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC>& B, int cnt, int lane) {
     }
 }
 
+// Does an id repeat among B.a_nbr[0 .. len0)?  An open-addressing set in the LDS the first sort is about to use (1 yes, 0 no,
+// -1 the column is too long for the set).  Exact: the answer decides whether the list order has to be restored.
+template <class BUF>
+__device__ __forceinline__ int flow_has_dup(BUF& B, int len0, int lane) {
+    int32_t* tab; int cap;
+    if constexpr (BUF::SMALL) { tab = reinterpret_cast<int32_t*>(B.rec); cap = (int)(sizeof(B.rec) / 4); }
+    else { tab = reinterpret_cast<int32_t*>(B.S->rec); cap = (int)(sizeof(B.S->rec) / 4); }
+    int bits = 31 - __builtin_clz((unsigned)cap);        // largest power of two that fits
+    if (2 * len0 > (1 << bits)) return -1;
+    while (bits > 6 && (1 << (bits - 1)) >= 2 * len0) --bits;   // no larger than needed: the table is cleared first
+    const int size = 1 << bits, mask = size - 1;
+    for (int q = lane; q < size; q += 64) tab[q] = -1;
+    WAVE_SYNC();
+    bool dup = false;
+    for (int i = lane; i < len0; i += 64) {
+        const int32_t id = B.a_nbr[i];
+        uint32_t hpos = ((uint32_t)id * 2654435761u) >> (32 - bits);
+        while (true) {
+            const int32_t old = atomicCAS(&tab[hpos], -1, id);
+            if (old == -1) break;
+            if (old == id) { dup = true; break; }
+            hpos = (hpos + 1) & (uint32_t)mask;
+        }
+    }
+    const bool any = __ballot(dup) != 0ull;
+    WAVE_SYNC();
+    return any ? 1 : 0;
+}
+
 __device__ __forceinline__ bool flow_abort(const FlowArrays& F) { return ag_ld(&F.ctrl[FC_ABORT]) != 0; }
 __device__ __forceinline__ void flow_fail(const FlowArrays& F, int32_t st) { __hip_atomic_fetch_max(&F.ctrl[FC_ABORT], st, RLX, AGT); }
 // A wait may last as long as the elimination itself (the last position of a clique waits for all the others), so it is not the
@@ -301,14 +330,21 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
     WAVE_SYNC();
     FSTAMP(1);
 
-    // ---- sort by neighbour id (std::sort semantics, :641-644) ----
-    for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
-    WAVE_SYNC();
-    flow_sort<false>(B, len0, lane);
-    {   // equal ids: the list order is part of the result -- appended entries newest first (descending tag), then sort again
-        bool dup = false;
-        for (int p = lane + 1; p < len0; p += 64) dup |= (B.R(p).key == B.R(p - 1).key);
-        if (__ballot(dup) != 0ull && napp > 1) {
+    // ---- sort by neighbour id (std::sort semantics, :641-644).  Where ids repeat, the list order is part of the result: the appended
+    //      entries are first put newest first (descending tag).  Whether they repeat is asked of a hash set, not of a sort ----
+    {
+        bool need_tag = false, sorted = false;
+        const int dupk = napp > 1 ? flow_has_dup(B, len0, lane) : 0;
+        if (dupk < 0) {   // (too long for the set: sort, look, and sort again if need be)
+            for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
+            WAVE_SYNC();
+            flow_sort<false>(B, len0, lane);
+            sorted = true;
+            bool dup = false;
+            for (int p = lane + 1; p < len0; p += 64) dup |= (B.R(p).key == B.R(p - 1).key);
+            need_tag = __ballot(dup) != 0ull;
+        } else need_tag = dupk > 0;
+        if (need_tag) {
             for (int i = lane; i < napp; i += 64) B.skey[i] = -(double)B.a_tag[i];
             WAVE_SYNC();
             flow_sort<false>(B, napp, lane);   // distinct keys
@@ -316,6 +352,9 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
             WAVE_SYNC();
             for (int i = lane; i < napp; i += 64) { B.a_nbr[i] = B.b_nbr[i]; B.a_twin[i] = B.b_twin[i]; B.a_val[i] = B.b_val[i]; }
             WAVE_SYNC();
+            sorted = false;
+        }
+        if (!sorted) {
             for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
             WAVE_SYNC();
             flow_sort<false>(B, len0, lane);
