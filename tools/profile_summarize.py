@@ -104,6 +104,7 @@ traffic = {
                f"profiles/{rnd}_pmc_fetch_write_bench_c3.csv; bytes = KB*1024, summed over the instantiations of a kernel; FETCH_SIZE is uncorrected "
                "(gfx950 reports 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section; narrower accesses uncalibrated)",
     "k_eliminate_batch": pick("rlap::k_eliminate_batch_t"),
+    "k_eliminate_flow": pick("rlap::k_eliminate_flow"),
     "k_sc_merge": pick("rlap::k_sc_merge_t"),
     "k_sc_merge_big": pick("rlap::k_sc_merge_big"),
     "k_sc_compact": pick("rlap::k_sc_compact"),
@@ -112,13 +113,54 @@ json.dump(traffic, open(os.path.join(PROF, f"{rnd}_pmc_traffic.json"), "w"), ind
 
 # 3. SQ counters of the elimination kernel
 sq = defaultdict(float)
+nlaunch = set()
 for r in csv.DictReader(open(one("sq/**/*counter_collection.csv"))):
     if short(r["Kernel_Name"]).startswith("rlap::k_eliminate_batch_t"):
         sq[r["Counter_Name"]] += float(r["Counter_Value"])
+        nlaunch.add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
 with open(os.path.join(PROF, f"{rnd}_sq_counters_k_eliminate_batch.csv"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --pmc SQ_* -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline; one launch of k_eliminate_batch_t<1,0,32>\n")
+    f.write(f"# rocprofv3 --kernel-trace --pmc SQ_* -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline; SUM over the {len(nlaunch)} launches of k_eliminate_batch_t<1,0,32> "
+            "in that command (1 timed + 3 of the unsorted-input line): divide by the launch count for one launch\n")
     for k in sorted(sq):
         f.write(f"\"{k}\",{sq[k]:.6f}\n")
+
+# 4. o_v = random at the same size: the dataflow kernel (rlap_flow.hip)
+hits_r = glob.glob(os.path.join(src, "trace_rand/**/*kernel_stats.csv"), recursive=True)
+if hits_r:
+    aggr = {}
+    for r in csv.DictReader(open(hits_r[0])):
+        a = aggr.setdefault(short(r["Name"]), [0, 0])
+        a[0] += int(r["Calls"]); a[1] += int(r["TotalDurationNs"])
+    totr = sum(v[1] for v in aggr.values())
+    with open(os.path.join(PROF, f"{rnd}_kernel_stats_bench_c3_random.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --o_v random --steps 3 --warmup 1 --no-cpu-baseline (7 calls of the op; rocPRIM template names shortened)\n")
+        f.write("kernel,calls,total_ms,avg_us,percent\n")
+        for k, (c, t) in sorted(aggr.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{k},{c},{t/1e6:.3f},{t/c/1e3:.1f},{100*t/totr:.3f}\n")
+hits_s = glob.glob(os.path.join(src, "sq_rand/**/*counter_collection.csv"), recursive=True)
+if hits_s:
+    sqr = defaultdict(float); nl = set(); grid = wg = None
+    for r in csv.DictReader(open(hits_s[0])):
+        if short(r["Kernel_Name"]).startswith("rlap::k_eliminate_flow"):
+            sqr[r["Counter_Name"]] += float(r["Counter_Value"])
+            nl.add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
+            grid = r.get("Grid_Size", grid); wg = r.get("Workgroup_Size", wg)
+    fr = wr = None
+    try:
+        fr = load(one("fetch_rand/**/*counter_collection.csv"), "FETCH_SIZE"); wr = load(one("write_rand/**/*counter_collection.csv"), "WRITE_SIZE")
+    except SystemExit:
+        pass
+    with open(os.path.join(PROF, f"{rnd}_sq_counters_k_eliminate_flow.csv"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc SQ_* -- python3 bench.py --o_v random --steps 1 --warmup 0 --no-cpu-baseline; SUM over the {len(nl)} launches of k_eliminate_flow "
+                f"(grid {grid} threads in workgroups of {wg}: one wave each, two per CU on every CU); SQ_BUSY_CU_CYCLES / SQ_BUSY_CYCLES = compute units busy on average\n")
+        for k in sorted(sqr):
+            f.write(f"\"{k}\",{sqr[k]:.6f}\n")
+        if fr and wr:
+            for k in fr:
+                if k.startswith("rlap::k_eliminate_flow"):
+                    f.write(f"\"FETCH_SIZE_KB_per_launch\",{sum(v for v, _ in fr[k]) / len(fr[k]):.1f}\n")
+                    f.write(f"\"WRITE_SIZE_KB_per_launch\",{sum(v for v, _ in wr.get(k, [(0, 0)])) / max(len(wr.get(k, [])), 1):.1f}\n")
+    print(dict(sqr))
 print(open(os.path.join(PROF, f"{rnd}_kernel_stats_bench_c3.csv")).read()[:1500])
 print(json.dumps(traffic, indent=1))
 print(dict(sq))
