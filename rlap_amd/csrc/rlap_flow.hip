@@ -37,20 +37,45 @@ __device__ __forceinline__ void ag_st(int32_t* p, int32_t v) { __hip_atomic_stor
 __device__ __forceinline__ unsigned long long ag_ld64(const unsigned long long* p) { return __hip_atomic_load(p, RLX, AGT); }
 __device__ __forceinline__ void ag_st64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, RLX, AGT); }
 __device__ __forceinline__ int32_t ag_add(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, RLX, AGT); }
-// a 16-byte entry as two 8-byte words (no reader while a writer is at it: rlap_flow.h)
-__device__ __forceinline__ Slot ag_ld_slot(const Slot* p) {
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-    const unsigned long long w0 = ag_ld64(q), w1 = ag_ld64(q + 1);
+// A 16-byte entry: ONE write-through / bypassing access (buffer_load/store_dwordx4 sc1) while the slot array is within a buffer
+// resource's 4 GB, else two 8-byte words (no reader while a writer is at it either way: rlap_flow.h).  One fabric request per entry
+// instead of two: under the load of a batch every request counts.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct SlotMem { __amdgpu_buffer_rsrc_t rsrc; bool wide; Slot* e; };
+__device__ __forceinline__ SlotMem slot_mem(const Arrays& A) {
+    SlotMem M;
+    const unsigned long long bytes = (unsigned long long)(uint32_t)A.slot_cap * 16ull;
+    M.wide = bytes < 0xFFFFFFF0ull;
+    M.rsrc = __builtin_amdgcn_make_buffer_rsrc(A.e, 0, M.wide ? (int)(uint32_t)bytes : 0, 0x00020000);
+    M.e = A.e;
+    return M;
+}
+__device__ __forceinline__ Slot ag_ld_slot(const SlotMem& M, int32_t sidx) {
     Slot s;
-    s.val = __longlong_as_double((long long)w0);
-    s.nbr = (int32_t)(uint32_t)(w1 & 0xFFFFFFFFull);
-    s.twin = (int32_t)(uint32_t)(w1 >> 32);
+    if (M.wide) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(M.rsrc, (int)((uint32_t)sidx * 16u), 0, 16);
+        s.val = __longlong_as_double((long long)((unsigned long long)v.x | ((unsigned long long)v.y << 32)));
+        s.nbr = (int32_t)v.z; s.twin = (int32_t)v.w;
+    } else {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(M.e + sidx);
+        const unsigned long long w0 = ag_ld64(q), w1 = ag_ld64(q + 1);
+        s.val = __longlong_as_double((long long)w0);
+        s.nbr = (int32_t)(uint32_t)(w1 & 0xFFFFFFFFull);
+        s.twin = (int32_t)(uint32_t)(w1 >> 32);
+    }
     return s;
 }
-__device__ __forceinline__ void ag_st_slot(Slot* p, double val, int32_t nbr, int32_t twin) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    ag_st64(q, (unsigned long long)__double_as_longlong(val));
-    ag_st64(q + 1, (unsigned long long)(uint32_t)nbr | ((unsigned long long)(uint32_t)twin << 32));
+__device__ __forceinline__ void ag_st_slot(const SlotMem& M, int32_t sidx, double val, int32_t nbr, int32_t twin) {
+    const unsigned long long w0 = (unsigned long long)__double_as_longlong(val);
+    if (M.wide) {
+        u32x4 v;
+        v.x = (uint32_t)w0; v.y = (uint32_t)(w0 >> 32); v.z = (uint32_t)nbr; v.w = (uint32_t)twin;
+        __builtin_amdgcn_raw_buffer_store_b128(v, M.rsrc, (int)((uint32_t)sidx * 16u), 0, 16);
+    } else {
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(M.e + sidx);
+        ag_st64(q, w0);
+        ag_st64(q + 1, (unsigned long long)(uint32_t)nbr | ((unsigned long long)(uint32_t)twin << 32));
+    }
 }
 __device__ __forceinline__ void ag_st_slot_val(Slot* p, double val) { ag_st64(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(val)); }
 #define DRAIN_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -282,6 +307,7 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
                                                const int32_t g, const int32_t vbase, const uint64_t gseed, int32_t* last_draws) {
     const int lane = lane_id();
     const uint64_t lt = lanemask_lt(lane);
+    const SlotMem M = slot_mem(A);
     long long ft_prev = P.prof ? wall_clock64() : 0;
     const long long ft_begin = ft_prev;
 #define FSTAMP(k) do { if (P.prof) { const long long _t = wall_clock64(); if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + (BUF::SMALL ? 0 : 20) + (k), (unsigned long long)(_t - ft_prev)); ft_prev = _t; } } while (0)
@@ -304,7 +330,7 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
             double val = 0; int32_t nb = 0, tw = 0, tg = 0;
             if (valid && base >= 0) {
                 const int32_t s = base + 1 + (i - chunk_start(c));
-                const Slot gsl = ag_ld_slot(A.e + s);
+                const Slot gsl = ag_ld_slot(M, s);
                 val = gsl.val; nb = gsl.nbr; tw = gsl.twin; tg = ag_ld(F.atag + s);
             }
             const bool live = valid && val > 0;
@@ -318,7 +344,7 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
             const int32_t s = s0 - lane;
             const bool valid = s >= cp0;
             double val = 0; int32_t nb = 0, tw = 0;
-            if (valid) { const Slot gsl = ag_ld_slot(A.e + s); val = gsl.val; nb = gsl.nbr; tw = gsl.twin; }
+            if (valid) { const Slot gsl = ag_ld_slot(M, s); val = gsl.val; nb = gsl.nbr; tw = gsl.twin; }
             const bool live = valid && val > 0;
             const uint64_t mask = __ballot(live);
             const int pos = len0 + popc64(mask & lt);
@@ -542,9 +568,9 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
         if (act) base = flow_chunk_base(A, F, P, k, c);
         if (act && base >= 0) {
             const int32_t s_n = base + 1 + (ai - chunk_start(c));
-            ag_st_slot(A.e + s_n, nw, a, s_r);
+            ag_st_slot(M, s_n, nw, a, s_r);
             ag_st(F.atag + s_n, (int32_t)(D + j));
-            ag_st_slot(A.e + s_r, nw, k, s_n);
+            ag_st_slot(M, s_r, nw, k, s_n);
             if (nw > 0) {
                 if (pk < pa && pa != FPOS_NONE) ag_add(&A.vr[a].key, 1);
                 if (pa < pk && pk != FPOS_NONE) ag_add(&A.vr[k].key, 1);
@@ -818,8 +844,9 @@ void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, cons
 
 // two shapes: one wave with a large LDS block, two workgroups per CU (a single large graph: what bounds the run is how fast a long
 // column is dealt with); or a small block, eight per CU (a batch of small graphs: what bounds the run is how many positions are in flight)
-void launch_flow_eliminate(bool many, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
-    if (many) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_SMALL, 2>), dim3(grid), dim3(64), 0, stream, A, F, P);
+void launch_flow_eliminate(int shape, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
+    if (shape == 2) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_SMALL, 2>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    else if (shape == 3) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_MID, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
     else hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
 }
 

@@ -114,6 +114,7 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t 
 // ---- dataflow elimination for o_v = random (rlap_flow.hip) ----
 constexpr int FLOW_EC = 896;              // column extent a wave handles in its own LDS (two one-wave workgroups per CU)
 constexpr int FLOW_EC_SMALL = 192;        // ... in the shape for batches of small graphs (eight per CU)
+constexpr int FLOW_EC_MID = 448;          // ... four per CU
 constexpr int FLOW_SCR_BYTES = 104;       // working storage per entry of a longer column (bump-allocated, rlap_flow.hip)
 struct FlowParams {
     const int32_t* vgraph;
@@ -129,7 +130,7 @@ struct FlowParams {
 };
 void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int64_t Eeff,
                        uint64_t* okey, uint32_t* oval, int gbits);
-void launch_flow_eliminate(bool many, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P);
+void launch_flow_eliminate(int shape, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P);
 void launch_debug_flow_sort(hipStream_t s, const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out, char* scr);
 void launch_flow_finish(hipStream_t s, const Arrays& A, const FlowArrays& F, GraphDesc* gd, int32_t N, int32_t G);
 void launch_flow_ro_count(hipStream_t s, const Arrays& A, const FlowArrays& F, const uint32_t* order, int32_t S, int32_t* cnt);

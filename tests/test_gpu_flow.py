@@ -89,7 +89,7 @@ GRAPHS = [("K4", clique(4), 4), ("K6", clique(6), 6), ("P9", path(9), 9), ("star
           ("BA3000_10", ba_graph(3000, 10, 2), 3000), ("BA400_40", ba_graph(400, 40, 5), 400)]
 
 
-@pytest.mark.parametrize("shape", ["1", "2"])
+@pytest.mark.parametrize("shape", ["1", "2", "3"])
 @pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
 def test_flow_matches_oracle(ops, flow_env, o_n, shape):
     """All graph families x weights x num_remove, both workgroup shapes (large LDS block / small blocks)."""
@@ -182,7 +182,7 @@ def test_flow_under_jitter_and_poison(ops, flow_env):
         for jit, poison in ((3, -1), (9, 170), (0, 255), (5, 0)):
             ops.debug_set_jitter(jit)
             ops.debug_set_poison(poison)
-            for shape in ("1", "2"):
+            for shape in ("1", "2", "3"):
                 flow_env["RLAP_FLOW_SHAPE"] = shape
                 b = call(ops, ei, None, n, n // 2, "asc", perm)
                 assert a.shape == b.shape and np.array_equal(a, b), (jit, poison, shape)
