@@ -107,7 +107,7 @@ struct FlowLds {
     __device__ __forceinline__ SRec& R(int i) { return rec[i]; }
 };
 // the same LDS block seen by a long column: only what the sorts touch (and afterwards the cumulative weights / new weights)
-constexpr int FLOW_LVL_BIG = 1024;   // long columns up to this many keys take the level-synchronous sort (16 elements per lane)
+constexpr int FLOW_LVL_BIG = 512;    // long columns up to this many keys take the level-synchronous sort (8 elements per lane: more live in scratch memory)
 template <int EC>
 struct FlowSortLds {
     static constexpr size_t AVAIL = offsetof(FlowLds<EC>, stk);
@@ -155,15 +155,17 @@ __device__ __forceinline__ void flow_sort(FlowLds<EC>& B, int cnt, int lane) {
     constexpr int REGMAX = (EC + 63) / 64;
     uint32_t* tab = reinterpret_cast<uint32_t*>(B.ksel);
     uint16_t* tab2 = reinterpret_cast<uint16_t*>(B.f_dup);
+    const WaveSortPtrs WP = {B.ulist, B.dlist, B.segmark, B.stk};
+    // (the level-synchronous form keeps 10 to 13 registers per element and lane: beyond 8 elements per lane it lives in scratch
+    // memory -- 370 reloads at 16 -- so longer arrays take partitions on top and that form for the segments of 512 and less)
     if (cnt <= 128) ok = wave_lvl_sort<SRec, Cmp, 2>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
     else if (REGMAX <= 4 || cnt <= 256) ok = wave_lvl_sort<SRec, Cmp, (REGMAX < 4 ? REGMAX : 4)>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
     else if (REGMAX <= 8 || cnt <= 512) ok = wave_lvl_sort<SRec, Cmp, (REGMAX < 8 ? REGMAX : 8)>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
-    else ok = wave_lvl_sort<SRec, Cmp, REGMAX>(B.rec, cnt, Cmp(), B.ulist, B.dlist, tab, tab2, lane);
+    else ok = wave_std_sort_hyb<SRec, Cmp, 8>(B.rec, cnt, Cmp(), WP, tab, tab2, lane);
     if (!ok) {   // depth limit: std::sort heap-sorts there; start over with the form that follows it
         WAVE_SYNC();
         for (int i = lane; i < cnt; i += 64) { B.rec[i].key = B.skey[i]; B.rec[i].idx = i; }
         WAVE_SYNC();
-        const WaveSortPtrs WP = {B.ulist, B.dlist, B.segmark, B.stk};
         wave_std_sort<SRec, Cmp, 0>(B.rec, cnt, Cmp(), WP, lane);
     }
     WAVE_SYNC();
