@@ -581,9 +581,9 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
             if (rc) return rc;
             FA.qorder = W.sval1.as<uint32_t>(); FA.Qclaim = (int32_t)nelim_total;
         }
-        int shape = G >= 16 ? 3 : 1;   // 1: 76 KB of LDS, two workgroups per CU; 3: 40 KB, four; 2: 17 KB, eight
-        if (const char* e = std::getenv("RLAP_FLOW_SHAPE")) { if (e[0] >= '1' && e[0] <= '3') shape = e[0] - '0'; }   // diagnostic override
-        unsigned grid = (shape == 2 ? 8u : shape == 3 ? 4u : 2u) * (unsigned)h->n_cu;
+        int shape = G >= 16 ? 3 : 1;   // 1: 76 KB of LDS, two workgroups per CU, four waves each (three help with long sorts); 4: the same with one wave; 3: 40 KB, four; 2: 17 KB, eight
+        if (const char* e = std::getenv("RLAP_FLOW_SHAPE")) { if (e[0] >= '1' && e[0] <= '4') shape = e[0] - '0'; }   // diagnostic override
+        unsigned grid = (shape == 2 ? 8u : shape == 3 ? 4u : 2u) * (unsigned)h->n_cu;   // (workgroups: one position each)
         if (const char* e = std::getenv("RLAP_FLOW_WAVES")) grid = (unsigned)std::max(1, std::atoi(e));
         launch_flow_eliminate(shape, grid, s, A, FA, FP);
         launch_flow_finish(s, A, FA, W.gd_d.as<GraphDesc>(), (int32_t)N, (int32_t)G);

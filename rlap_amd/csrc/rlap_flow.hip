@@ -108,30 +108,71 @@ struct FlowLds {
 };
 // the same LDS block seen by a long column: only what the sorts touch (and afterwards the cumulative weights / new weights)
 constexpr int FLOW_LVL_BIG = 512;    // long columns up to this many keys take the level-synchronous sort (8 elements per lane: more live in scratch memory)
-template <int EC>
+template <int EC, int NW>
 struct FlowSortLds {
     static constexpr size_t AVAIL = offsetof(FlowLds<EC>, stk);
     static constexpr int LVL = (AVAIL >= (size_t)FLOW_LVL_BIG * 26 + 4096) ? FLOW_LVL_BIG : 0;
-    static constexpr int BIGL = (int)((AVAIL - (size_t)LVL * 6 - 64) / 21) & ~7;   // records + two 16-bit lists + marks per entry
+    static constexpr int NT = LVL > 0 ? NW : 1;                                   // one pair of tables per sorting wave
+    static constexpr int BIGL = (int)((AVAIL - (size_t)LVL * 6 * NT - 512) / 23) & ~7;   // records + two 16-bit lists + marks + queue share per entry
+    static constexpr int QCAP = NW > 1 ? BIGL / 17 + 8 : 1;
     SRec rec[BIGL];
     uint16_t ulist[BIGL + 2], dlist[BIGL + 2];
     uint32_t segmark[BIGL / 32 + 2];
-    uint32_t tab[LVL > 0 ? LVL : 1];
-    uint16_t tab2[LVL > 0 ? LVL : 2];
+    uint32_t tab[LVL > 0 ? NT * LVL : 1];
+    uint16_t tab2[LVL > 0 ? NT * LVL : 2];
+    int32_t segq[2 * 3 * QCAP];
+    int32_t qcnt[4];
 };
-template <int EC>
+// ... and by a column too long for that: the sort moves 16-bit indices, the keys stay where they are (8 + 2 + 4 bytes per entry)
+template <int EC, int NW>
+struct FlowIdxLds {
+    static constexpr size_t AVAIL = offsetof(FlowLds<EC>, stk);
+    static constexpr int LVL = FlowSortLds<EC, NW>::LVL;
+    static constexpr int NT = LVL > 0 ? NW : 1;
+    static constexpr int IDXL = (int)((AVAIL - (size_t)LVL * 6 * NT - 512) / 17) & ~7;
+    static constexpr int QCAP = NW > 1 ? IDXL / 17 + 8 : 1;
+    double key[IDXL];
+    uint16_t idx[IDXL + 2], ulist[IDXL + 2], dlist[IDXL + 2];
+    uint32_t segmark[IDXL / 32 + 2];
+    uint32_t tab[LVL > 0 ? NT * LVL : 1];
+    uint16_t tab2[LVL > 0 ? NT * LVL : 2];
+    int32_t segq[2 * 3 * QCAP];
+    int32_t qcnt[4];
+};
+struct IdxKeyLess { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { return key[a] < key[b]; } };
+struct IdxKeyGreater { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { return key[a] > key[b]; } };
+enum { FCMD_SORT = 1, FCMD_EXIT = 2, FCMD_RECUR = 3 };
+template <int EC, int NW>
 struct FlowBig {
     static constexpr bool SMALL = false;
-    FlowSortLds<EC>* S;      // derived from the kernel's __shared__ block (the compiler sees LDS addresses)
+    FlowSortLds<EC, NW>* S;  // derived from the kernel's __shared__ block (the compiler sees LDS addresses)
+    FlowIdxLds<EC, NW>* X;   // the same block, index-sort view
     int32_t* stk; int32_t* tmp;
-    bool lds;                // sort records in LDS (else in the scratch: grec, gulist, gdlist, gsegmark)
+    int32_t* cmd;            // NW > 1: the workgroup's helper waves are told here (FCMD_*, kind, count, descending)
+    int kind;                // the sort's records: 1 in LDS, 2 indices + keys in LDS, 0 in the scratch (grec, gulist, gdlist, gsegmark)
     SRec* grec; uint16_t *gulist, *gdlist; uint32_t* gsegmark;
     double *a_val, *b_val, *skey, *cum_, *newv_;
     int32_t *a_nbr, *a_twin, *a_tag, *b_nbr, *b_twin, *b_dup, *b_pos, *f_dup, *f_pos, *ksel;
     __device__ __forceinline__ double* cum() { return cum_; }
     __device__ __forceinline__ double* newv() { return newv_; }
-    __device__ __forceinline__ SRec R(int i) const { return lds ? S->rec[i] : grec[i]; }
+    __device__ __forceinline__ SRec R(int i) const {
+        if (kind == 1) return S->rec[i];
+        if (kind == 2) { SRec r; const int q = X->idx[i]; r.key = X->key[q]; r.idx = q; r.aux = 0; return r; }
+        return grec[i];
+    }
 };
+// The multi-wave sort of a long column whose records (kind 1) or indices + keys (kind 2) are staged in the workgroup's LDS:
+// called by ALL NW waves (the owner and its helpers) with the same arguments.
+template <int EC, int NW>
+__device__ __noinline__ bool flow_block_sort(FlowSortLds<EC, NW>* S, FlowIdxLds<EC, NW>* X, int kind, int cnt, int greater, int wave, int lane) {
+    constexpr int LREG = FLOW_LVL_BIG / 64;
+    if (kind == 1) {
+        if (greater) return block_std_sort_lvl<SRec, SRecGreaterKey, NW, LREG>(S->rec, cnt, SRecGreaterKey(), S->ulist, S->dlist, S->segmark, S->segq, S->qcnt, FlowSortLds<EC, NW>::QCAP, S->tab, S->tab2, wave, lane);
+        return block_std_sort_lvl<SRec, SRecLessKey, NW, LREG>(S->rec, cnt, SRecLessKey(), S->ulist, S->dlist, S->segmark, S->segq, S->qcnt, FlowSortLds<EC, NW>::QCAP, S->tab, S->tab2, wave, lane);
+    }
+    if (greater) return block_std_sort_lvl<uint16_t, IdxKeyGreater, NW, LREG>(X->idx, cnt, IdxKeyGreater{X->key}, X->ulist, X->dlist, X->segmark, X->segq, X->qcnt, FlowIdxLds<EC, NW>::QCAP, X->tab, X->tab2, wave, lane);
+    return block_std_sort_lvl<uint16_t, IdxKeyLess, NW, LREG>(X->idx, cnt, IdxKeyLess{X->key}, X->ulist, X->dlist, X->segmark, X->segq, X->qcnt, FlowIdxLds<EC, NW>::QCAP, X->tab, X->tab2, wave, lane);
+}
 static_assert(FLOW_SCR_BYTES >= 16 + 5 * 8 + 10 * 4 + 2 * 2 + 1 && FLOW_SCR_BYTES % 8 == 0, "records, five doubles, ten ints, two 16-bit lists and the segment marks per entry");
 
 // std::sort order of the staged keys B.skey[0..cnt) into the records {key, source index} (rlap_wave_sort.h)
@@ -170,28 +211,50 @@ __device__ __forceinline__ void flow_sort(FlowLds<EC>& B, int cnt, int lane) {
     }
     WAVE_SYNC();
 }
-template <bool GREATER, int EC>
-__device__ __forceinline__ void flow_sort(FlowBig<EC>& B, int cnt, int lane) {
+template <bool GREATER, int EC, int NW>
+__device__ __forceinline__ void flow_sort(FlowBig<EC, NW>& B, int cnt, int lane) {
     typedef typename std::conditional<GREATER, SRecGreaterKey, SRecLessKey>::type Cmp;
-    if (B.lds) {
-        FlowSortLds<EC>& S = *B.S;
-        for (int i = lane; i < cnt; i += 64) { S.rec[i].key = B.skey[i]; S.rec[i].idx = i; }
-        WAVE_SYNC();
+    typedef typename std::conditional<GREATER, IdxKeyGreater, IdxKeyLess>::type ICmp;
+    constexpr int LVL = FlowSortLds<EC, NW>::LVL;
+    if (B.kind == 1 || B.kind == 2) {
+        FlowSortLds<EC, NW>& S = *B.S;
+        FlowIdxLds<EC, NW>& X = *B.X;
+        auto stage = [&]() {
+            if (B.kind == 1) { for (int i = lane; i < cnt; i += 64) { S.rec[i].key = B.skey[i]; S.rec[i].idx = i; } }
+            else { for (int i = lane; i < cnt; i += 64) { X.key[i] = B.skey[i]; X.idx[i] = (uint16_t)i; } }
+            WAVE_SYNC();
+        };
+        stage();
         bool ok = false;
-        if constexpr (FlowSortLds<EC>::LVL > 0) {
-            if (cnt <= FlowSortLds<EC>::LVL) {
-                ok = wave_lvl_sort<SRec, Cmp, FlowSortLds<EC>::LVL / 64>(S.rec, cnt, Cmp(), S.ulist, S.dlist, S.tab, S.tab2, lane);
-                if (!ok) { WAVE_SYNC(); for (int i = lane; i < cnt; i += 64) { S.rec[i].key = B.skey[i]; S.rec[i].idx = i; } WAVE_SYNC(); }
+        if constexpr (NW > 1 && LVL > 0) {
+            if (cnt > LVL) {   // worth the helpers: partitions level by level over the workgroup's waves, the level-synchronous form per short segment
+                if (lane == 0) { B.cmd[1] = B.kind; B.cmd[2] = cnt; B.cmd[3] = GREATER ? 1 : 0; B.cmd[0] = FCMD_SORT; }
+                __syncthreads();
+                ok = flow_block_sort<EC, NW>(B.S, B.X, B.kind, cnt, GREATER ? 1 : 0, 0, lane);
+                __syncthreads();
+                if (!ok) stage();
+                else { WAVE_SYNC(); return; }
             }
         }
-        if (!ok) {
+        if (B.kind == 1) {
             const WaveSortPtrs WP = {S.ulist, S.dlist, S.segmark, B.stk};
-            if constexpr (FlowSortLds<EC>::LVL > 0) {
-                // beyond the level-synchronous form's reach: partitions on top, that form for every segment it can take
-                if (cnt > FlowSortLds<EC>::LVL) ok = wave_std_sort_hyb<SRec, Cmp, FlowSortLds<EC>::LVL / 64>(S.rec, cnt, Cmp(), WP, S.tab, S.tab2, lane);
-                if (!ok && cnt > FlowSortLds<EC>::LVL) { WAVE_SYNC(); for (int i = lane; i < cnt; i += 64) { S.rec[i].key = B.skey[i]; S.rec[i].idx = i; } WAVE_SYNC(); }
+            if constexpr (LVL > 0) {
+                if (!ok && !(NW > 1 && cnt > LVL)) {
+                    ok = wave_std_sort_hyb<SRec, Cmp, LVL / 64>(S.rec, cnt, Cmp(), WP, S.tab, S.tab2, lane);
+                    if (!ok) stage();
+                }
             }
             if (!ok) wave_std_sort<SRec, Cmp, 0>(S.rec, cnt, Cmp(), WP, lane);
+        } else {
+            const ICmp less{X.key};
+            const WaveSortPtrs WP = {X.ulist, X.dlist, X.segmark, B.stk};
+            if constexpr (LVL > 0) {
+                if (!ok && !(NW > 1 && cnt > LVL)) {
+                    ok = wave_std_sort_hyb<uint16_t, ICmp, LVL / 64>(X.idx, cnt, less, WP, X.tab, X.tab2, lane);
+                    if (!ok) stage();
+                }
+            }
+            if (!ok) wave_std_sort<uint16_t, ICmp, 0>(X.idx, cnt, less, WP, lane);
         }
         WAVE_SYNC();
     } else {
@@ -213,7 +276,7 @@ template <class BUF>
 __device__ __forceinline__ int flow_has_dup(BUF& B, int len0, int lane) {
     int32_t* tab; int cap;
     if constexpr (BUF::SMALL) { tab = reinterpret_cast<int32_t*>(B.rec); cap = (int)(sizeof(B.rec) / 4); }
-    else { tab = reinterpret_cast<int32_t*>(B.S->rec); cap = (int)(sizeof(B.S->rec) / 4); }
+    else { tab = reinterpret_cast<int32_t*>(B.S->rec); cap = (int)(sizeof(B.S->rec) / 4); }   // (the records' part of the sort overlay)
     int bits = 31 - __builtin_clz((unsigned)cap);        // largest power of two that fits
     if (2 * len0 > (1 << bits)) return -1;
     while (bits > 6 && (1 << (bits - 1)) >= 2 * len0) --bits;   // no larger than needed: the table is cleared first
@@ -298,13 +361,56 @@ __device__ __forceinline__ int32_t flow_chunk_base(const Arrays& A, const FlowAr
     return b < 0 ? FD_FAIL : b;
 }
 
+// The two serial loops of an elimination (:728-779), by ONE lane -- the operation order is the result.  Values are fetched eight
+// at a time (the loop's own latency is the floating-point chain, not the LDS).  `v` and `newv` may be the same array.
+__device__ __forceinline__ double flow_cumsum(const double* v, double* cum, int m) {
+    double csum = 0;
+    int j0 = 0;
+    for (; j0 + 8 <= m; j0 += 8) {
+        double vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = v[j0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { csum += vv[u]; cum[j0 + u] = csum; }
+    }
+    for (; j0 < m; ++j0) { csum += v[j0]; cum[j0] = csum; }
+    return csum;
+}
+__device__ __forceinline__ void flow_recur(const double* v, double* newv, int m, double csum) {
+    double wdeg = csum, colScale = 1;
+    int j0 = 0;
+    for (; j0 + 8 <= m - 1; j0 += 8) {
+        double vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vv[u] = v[j0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double w = vv[u] * colScale;
+            const double f = w / wdeg;
+            const double omf = 1 - f;
+            newv[j0 + u] = f * omf * wdeg;
+            colScale = colScale * omf;
+            wdeg = wdeg * omf * omf;
+        }
+    }
+    for (; j0 < m - 1; ++j0) {
+        const double w = v[j0] * colScale;
+        const double f = w / wdeg;
+        const double omf = 1 - f;
+        newv[j0] = f * omf * wdeg;
+        colScale = colScale * omf;
+        wdeg = wdeg * omf * omf;
+    }
+}
+constexpr int FLOW_HELP_MIN = 24;   // shorter columns keep the recurrence on the owning wave (the hand-over is two workgroup barriers)
+
 #define FLOW_JITTER(tag) do { if (P.jitter > 0) { const uint32_t _h = ((uint32_t)idx * 2654435761u + (uint32_t)(tag) * 40503u) >> 9; \
         if ((_h & 3u) == 0u) for (int _q = 0; _q < P.jitter * (int)(1 + ((_h >> 2) & 7u)); ++_q) __builtin_amdgcn_s_sleep(8); } } while (0)
 
 // One position of the order, from the gathered column to the release of the neighbours.  `ext` slots are read (appended + CSR,
 // dead ones included); the live ones must fit `cap`.  Returns false when the launch is being abandoned.
-template <class BUF>
-__device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, const FlowArrays& F, const FlowParams& P, BUF& B, const int32_t cap,
+template <int NWK, class BUF>
+__device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON, const Arrays& A, const FlowArrays& F, const FlowParams& P, BUF& B, const int32_t cap,
                                                const int32_t idx, const int32_t v, const int32_t cp0, const int32_t cp1, const int32_t acnt,
                                                const int32_t g, const int32_t vbase, const uint64_t gseed, int32_t* last_draws) {
     const int lane = lane_id();
@@ -437,68 +543,34 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
     // ---- cumulative weights and the f / colScale / wdeg recurrence (:728-779): one lane, the operation order is the result ----
     double* cum = B.cum();
     double* newv = B.newv();
-    if constexpr (!BUF::SMALL) {
-        if (B.lds && 2 * m <= 2 * B.S->BIGL) {   // the records are free now: the two serial loops run over LDS
-            double* lc = reinterpret_cast<double*>(B.S->rec);
-            for (int j = lane; j < m; j += 64) lc[B.S->BIGL + j] = B.a_val[j];
+    const double* vsrc = B.a_val;
+    bool in_lds = BUF::SMALL;
+    char* lbase;
+    if constexpr (BUF::SMALL) lbase = reinterpret_cast<char*>(&B);
+    else {
+        lbase = reinterpret_cast<char*>(B.S);
+        constexpr int LCAP = (int)(sizeof(*B.S) / 16);   // the sort's LDS is free now: both loops and the sampling run over it (cumulative sums | values, then new weights)
+        if (m <= LCAP) {
+            double* lc = reinterpret_cast<double*>(B.S);
+            for (int j = lane; j < m; j += 64) lc[LCAP + j] = B.a_val[j];
             WAVE_SYNC();
-            if (lane == 0) {
-                double csum = 0;
-                for (int j = 0; j < m; ++j) { csum += lc[B.S->BIGL + j]; lc[j] = csum; }
-                double wdeg = csum, colScale = 1;
-                for (int j = 0; j < m - 1; ++j) {
-                    const double w = lc[B.S->BIGL + j] * colScale;
-                    const double f = w / wdeg;
-                    const double omf = 1 - f;
-                    lc[B.S->BIGL + j] = f * omf * wdeg;
-                    colScale = colScale * omf;
-                    wdeg = wdeg * omf * omf;
-                }
-            }
-            WAVE_SYNC();
-            for (int j = lane; j < m; j += 64) { cum[j] = lc[j]; newv[j] = lc[B.S->BIGL + j]; }
-            WAVE_SYNC();
-        } else if (lane == 0) {
-            double csum = 0;
-            for (int j = 0; j < m; ++j) { csum += B.a_val[j]; cum[j] = csum; }
-            double wdeg = csum, colScale = 1;
-            for (int j = 0; j < m - 1; ++j) {
-                const double w = B.a_val[j] * colScale;
-                const double f = w / wdeg;
-                const double omf = 1 - f;
-                newv[j] = f * omf * wdeg;
-                colScale = colScale * omf;
-                wdeg = wdeg * omf * omf;
-            }
-        }
-    } else
-    if (lane == 0) {
-        double csum = 0;
-        for (int j0 = 0; j0 < m; j0 += 8) {
-            double vv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = (j0 + u < m) ? B.a_val[j0 + u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (j0 + u < m) { csum += vv[u]; cum[j0 + u] = csum; }
-        }
-        double wdeg = csum, colScale = 1;
-        for (int j0 = 0; j0 < m - 1; j0 += 8) {
-            double vv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = (j0 + u < m - 1) ? B.a_val[j0 + u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (j0 + u < m - 1) {
-                    const double w = vv[u] * colScale;
-                    const double f = w / wdeg;
-                    const double omf = 1 - f;
-                    newv[j0 + u] = f * omf * wdeg;
-                    colScale = colScale * omf;
-                    wdeg = wdeg * omf * omf;
-                }
-            }
+            cum = lc; newv = lc + LCAP; vsrc = newv; in_lds = true;
         }
     }
+    double csum_l0 = 0;
+    if (lane == 0) csum_l0 = flow_cumsum(vsrc, cum, m);
+    // the recurrence is needed at the commit only: the workgroup's helper wave runs it while this one waits for its uniforms and samples
+    bool helped = false;
+    if constexpr (NWK > 1) helped = in_lds && m >= FLOW_HELP_MIN;
+    if (helped) {
+        if (lane == 0) {
+            const long long cb = __double_as_longlong(csum_l0);
+            cmd[1] = m; cmd[2] = (int32_t)(reinterpret_cast<const char*>(vsrc) - lbase); cmd[3] = (int32_t)(reinterpret_cast<char*>(newv) - lbase);
+            cmd[4] = (int32_t)(uint32_t)((unsigned long long)cb & 0xFFFFFFFFull); cmd[5] = (int32_t)(uint32_t)((unsigned long long)cb >> 32);
+            cmd[0] = FCMD_RECUR;
+        }
+        __syncthreads();
+    } else if (lane == 0) flow_recur(vsrc, newv, m, csum_l0);
     WAVE_SYNC();
 
     FSTAMP(5);
@@ -527,13 +599,13 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
             }
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63) == 0) {
-                if (flow_abort(F)) return false;
-                if (flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); return false; }
+                if (flow_abort(F)) { if (helped) __syncthreads(); return false; }
+                if (flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); if (helped) __syncthreads(); return false; }
             }
         }
         D = sum;
     }
-    if (D + cdraw > A.rng_len) { flow_fail(F, ST_RNG_OVERFLOW); return false; }
+    if (D + cdraw > A.rng_len) { flow_fail(F, ST_RNG_OVERFLOW); if (helped) __syncthreads(); return false; }
     if (lane == 0) ag_st64(F.lb + idx, LB_VALID | LB_PREFIX | (unsigned long long)(D + cdraw));
     *last_draws = (int32_t)(D + cdraw);
     FSTAMP(6);
@@ -549,6 +621,7 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
     }
     WAVE_SYNC();
 
+    if (helped) __syncthreads();   // the helper's new weights are in place
     FSTAMP(7);
     // ---- commit (:766-776): the new entry is appended to column k, the twin rewritten in place; live pairs are counted at the end that
     //      comes later; then my last neighbour's entry and the merged duplicates' twins die (:791-792, :655) ----
@@ -602,24 +675,44 @@ __device__ __forceinline__ bool flow_eliminate(const int ON, const Arrays& A, co
 // The persistent kernel: one wave per workgroup; grid = as many as are wanted in flight (they need not all be resident: a
 // workgroup that starts late claims later positions, and what a position waits for is always held by a running wave).
 // ---------------------------------------------------------------------------
-template <int EC, int MINW>
-__global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArrays F, FlowParams P) {
+template <int EC, int MINW, int NW>
+__global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, FlowArrays F, FlowParams P) {
     __shared__ FlowLds<EC> L;
-    static_assert(sizeof(FlowSortLds<EC>) <= offsetof(FlowLds<EC>, stk), "the long-column sort does not fit the wave's LDS");
+    __shared__ int32_t s_cmd[8];
+    static_assert(sizeof(FlowSortLds<EC, NW>) <= offsetof(FlowLds<EC>, stk) && sizeof(FlowIdxLds<EC, NW>) <= offsetof(FlowLds<EC>, stk), "the long-column sort does not fit the wave's LDS");
     const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
     const int ON = A.o_n;
     if (P.poison >= 0) {
         uint32_t* const w = reinterpret_cast<uint32_t*>(&L);
         const uint32_t pat = 0x01010101u * (uint32_t)(P.poison & 0xFF);
-        for (size_t q = lane; q < sizeof(L) / 4; q += 64) w[q] = pat;
-        WAVE_SYNC();
+        for (size_t q = threadIdx.x; q < sizeof(L) / 4; q += 64 * NW) w[q] = pat;
+        __syncthreads();
     }
     {   // rejected input (the setup kernels' flags are read here, not on the host): nothing is eliminated
         int32_t bad = 0;
         if (P.in_flags[FLAG_RANGE]) bad = ST_INDEX_RANGE;
         else if (P.in_flags[FLAG_CROSS] || P.in_flags[FLAG_PERM]) bad = ST_BAD_ARG;
         else if (P.in_acc[2] != 0.0 || !(P.in_acc[0] <= 1e-24 * P.in_acc[1])) bad = ST_NOT_SYMMETRIC;
-        if (bad) { if (lane == 0 && blockIdx.x == 0) flow_fail(F, bad); return; }
+        if (bad) { if (threadIdx.x == 0 && blockIdx.x == 0) flow_fail(F, bad); return; }
+    }
+    if constexpr (NW > 1) {
+        // waves 1 .. NW-1 only help wave 0 with the sorts of its long columns: they sleep at the workgroup barrier until told
+        if (wave > 0) {
+            while (true) {
+                __syncthreads();
+                if (s_cmd[0] == FCMD_EXIT) break;
+                if (s_cmd[0] == FCMD_RECUR) {
+                    if (wave == 1 && lane == 0) {
+                        const unsigned long long cb = (unsigned long long)(uint32_t)s_cmd[4] | ((unsigned long long)(uint32_t)s_cmd[5] << 32);
+                        flow_recur(reinterpret_cast<const double*>(reinterpret_cast<char*>(&L) + s_cmd[2]), reinterpret_cast<double*>(reinterpret_cast<char*>(&L) + s_cmd[3]), s_cmd[1], __longlong_as_double((long long)cb));
+                    }
+                } else
+                flow_block_sort<EC, NW>(reinterpret_cast<FlowSortLds<EC, NW>*>(&L), reinterpret_cast<FlowIdxLds<EC, NW>*>(&L), s_cmd[1], s_cmd[2], s_cmd[3], wave, lane);
+                __syncthreads();
+            }
+            return;
+        }
     }
     while (true) {
         long long mt0 = P.prof ? wall_clock64() : 0;
@@ -661,7 +754,7 @@ __global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArray
         int32_t draws = 0;
         bool ok;
         if (ext <= EC) {
-            ok = flow_eliminate(ON, A, F, P, L, EC, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+            ok = flow_eliminate<NW>(s_cmd, ON, A, F, P, L, EC, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
         } else {
             // long column: the arrays come from the bump allocator; the sort's records, stop lists and tables stay in LDS while they fit
             int32_t b0 = 0;
@@ -670,7 +763,8 @@ __global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArray
             b0 = __builtin_amdgcn_readfirstlane(b0);
             if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); break; }
             char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
-            FlowBig<EC> Gb;
+            FlowBig<EC, NW> Gb;
+            Gb.cmd = s_cmd;
             const int64_t n8 = want;
             double* d = reinterpret_cast<double*>(base);
             Gb.a_val = d; Gb.b_val = d + n8; Gb.skey = d + 2 * n8; Gb.cum_ = d + 3 * n8; Gb.newv_ = d + 4 * n8;
@@ -682,15 +776,20 @@ __global__ __launch_bounds__(64, MINW) void k_eliminate_flow(Arrays A, FlowArray
             Gb.gulist = reinterpret_cast<uint16_t*>(q + 16 * n8);
             Gb.gdlist = Gb.gulist + n8;
             Gb.gsegmark = reinterpret_cast<uint32_t*>(Gb.gdlist + n8);
-            Gb.S = reinterpret_cast<FlowSortLds<EC>*>(&L);
+            Gb.S = reinterpret_cast<FlowSortLds<EC, NW>*>(&L);
+            Gb.X = reinterpret_cast<FlowIdxLds<EC, NW>*>(&L);
             Gb.stk = L.stk; Gb.tmp = L.tmp;
-            Gb.lds = FLOW_BIG_IN_LDS && ext <= FlowSortLds<EC>::BIGL;
-            ok = flow_eliminate(ON, A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+            Gb.kind = !FLOW_BIG_IN_LDS ? 0 : (ext <= FlowSortLds<EC, NW>::BIGL ? 1 : (ext <= FlowIdxLds<EC, NW>::IDXL ? 2 : 0));
+            ok = flow_eliminate<NW>(s_cmd, ON, A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
             if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_LONG], 1, RLX, AGT);
         }
         if (!ok) break;
         // the last position of a graph files the graph's draw count
         if (lane == 0 && (idx + 1 >= F.Q || F.qv[idx + 1] < 0)) P.gd[g].n_draws = draws;
+    }
+    if constexpr (NW > 1) {   // every way out of the loop ends here: the helpers are sent home
+        if (lane == 0) s_cmd[0] = FCMD_EXIT;
+        __syncthreads();
     }
 }
 
@@ -808,28 +907,43 @@ __global__ void k_flow_ro_store(Arrays A, FlowArrays F, const int32_t* __restric
 // test hook (rlap_debug_wave_sort, desc bit 5): the long-column sort of the dataflow kernel -- one workgroup sorts one array of
 // doubles, records in LDS (level-synchronous / hybrid / partition forms by length) or, with desc bit 6 or beyond the LDS block, in
 // global scratch; returns the permutation.  Compared with std::sort itself by tests/test_gpu_flow.py.
-__global__ __launch_bounds__(64) void k_debug_flow_sort(const double* __restrict__ keys, const int32_t* __restrict__ offs, int32_t narr, int32_t desc,
-                                                        int32_t* __restrict__ perm_out, char* __restrict__ scr) {
+__global__ __launch_bounds__(64 * FLOW_NW) void k_debug_flow_sort(const double* __restrict__ keys, const int32_t* __restrict__ offs, int32_t narr, int32_t desc,
+                                                                  int32_t* __restrict__ perm_out, char* __restrict__ scr) {
     __shared__ FlowLds<FLOW_EC> L;
-    const int lane = lane_id();
+    __shared__ int32_t s_cmd[8];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (wave > 0) {   // helpers, as in k_eliminate_flow
+        while (true) {
+            __syncthreads();
+            if (s_cmd[0] == FCMD_EXIT) break;
+            flow_block_sort<FLOW_EC, FLOW_NW>(reinterpret_cast<FlowSortLds<FLOW_EC, FLOW_NW>*>(&L), reinterpret_cast<FlowIdxLds<FLOW_EC, FLOW_NW>*>(&L), s_cmd[1], s_cmd[2], s_cmd[3], wave, lane);
+            __syncthreads();
+        }
+        return;
+    }
     for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
         const int32_t o = offs[arr], n = offs[arr + 1] - o;
-        FlowBig<FLOW_EC> B;
-        B.S = reinterpret_cast<FlowSortLds<FLOW_EC>*>(&L); B.stk = L.stk; B.tmp = L.tmp;
-        B.lds = !(desc & 64) && n <= FlowSortLds<FLOW_EC>::BIGL;
+        FlowBig<FLOW_EC, FLOW_NW> B;
+        B.S = reinterpret_cast<FlowSortLds<FLOW_EC, FLOW_NW>*>(&L); B.X = reinterpret_cast<FlowIdxLds<FLOW_EC, FLOW_NW>*>(&L); B.stk = L.stk; B.tmp = L.tmp; B.cmd = s_cmd;
+        B.kind = (desc & 64) ? 0 : ((desc & 128) ? (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0) : (n <= FlowSortLds<FLOW_EC, FLOW_NW>::BIGL ? 1 : (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0)));
         B.skey = const_cast<double*>(keys) + o;
         char* base = scr + 32 * (int64_t)o + 64 * (int64_t)arr;
         B.grec = reinterpret_cast<SRec*>(base);
         B.gulist = reinterpret_cast<uint16_t*>(base + 16 * (int64_t)n);
         B.gdlist = B.gulist + (n + 2);
         B.gsegmark = reinterpret_cast<uint32_t*>(base + 20 * (int64_t)n + 8);
+        const long long t0 = wall_clock64();
         if (desc & 1) flow_sort<true>(B, n, lane); else flow_sort<false>(B, n, lane);
+        const long long t1 = wall_clock64();
         for (int q = lane; q < n; q += 64) perm_out[o + q] = B.R(q).idx;
+        if ((desc & 256) && lane == 0 && n > 0) perm_out[o] = (int32_t)(t1 - t0);   // diagnostic: the sort's duration in 10 ns ticks instead of the first index
         WAVE_SYNC();
     }
+    if (lane == 0) s_cmd[0] = FCMD_EXIT;
+    __syncthreads();
 }
 void launch_debug_flow_sort(hipStream_t s, const double* keys, const int32_t* offs, int32_t narr, int32_t desc, int32_t* perm_out, char* scr) {
-    hipLaunchKernelGGL(k_debug_flow_sort, dim3((unsigned)std::min<int32_t>(narr, 512)), dim3(64), 0, s, keys, offs, narr, desc, perm_out, scr);
+    hipLaunchKernelGGL(k_debug_flow_sort, dim3((unsigned)std::min<int32_t>(narr, 512)), dim3(64 * FLOW_NW), 0, s, keys, offs, narr, desc, perm_out, scr);
 }
 
 void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p,
@@ -847,9 +961,10 @@ void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, cons
 // two shapes: one wave with a large LDS block, two workgroups per CU (a single large graph: what bounds the run is how fast a long
 // column is dealt with); or a small block, eight per CU (a batch of small graphs: what bounds the run is how many positions are in flight)
 void launch_flow_eliminate(int shape, unsigned grid, hipStream_t stream, const Arrays& A, const FlowArrays& F, const FlowParams& P) {
-    if (shape == 2) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_SMALL, 2>), dim3(grid), dim3(64), 0, stream, A, F, P);
-    else if (shape == 3) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_MID, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
-    else hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    if (shape == 2) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_SMALL, 2, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    else if (shape == 3) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC_MID, 1, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    else if (shape == 4) hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC, 1, 1>), dim3(grid), dim3(64), 0, stream, A, F, P);
+    else hipLaunchKernelGGL((k_eliminate_flow<FLOW_EC, 1, FLOW_NW>), dim3(grid), dim3(64 * FLOW_NW), 0, stream, A, F, P);
 }
 
 void launch_flow_finish(hipStream_t s, const Arrays& A, const FlowArrays& F, GraphDesc* gd, int32_t N, int32_t G) {

@@ -115,6 +115,7 @@ void launch_eliminate_batch(int o_v, int o_n, unsigned G, int n_cu, hipStream_t 
 constexpr int FLOW_EC = 896;              // column extent a wave handles in its own LDS (two one-wave workgroups per CU)
 constexpr int FLOW_EC_SMALL = 192;        // ... in the shape for batches of small graphs (eight per CU)
 constexpr int FLOW_EC_MID = 448;          // ... four per CU
+constexpr int FLOW_NW = 2;                // waves per workgroup in the large shape: wave 0 owns the position, the others help with the sorts of its long columns
 constexpr int FLOW_SCR_BYTES = 104;       // working storage per entry of a longer column (bump-allocated, rlap_flow.hip)
 struct FlowParams {
     const int32_t* vgraph;

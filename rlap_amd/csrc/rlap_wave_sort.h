@@ -542,6 +542,160 @@ __device__ bool wave_std_sort_hyb(T* a, int n, Less less, const WaveSortPtrs W_,
 }
 
 // ---------------------------------------------------------------------------
+// One array shared by NW waves of a workgroup, level by level (the form of rlap_kernels.hip::block_std_sort), with the
+// level-synchronous form for every segment of 64*LREG elements and less: a level's segments are dealt to the waves; a long one is
+// partitioned by its wave (stop lists at the segment's own offsets) and its parts are queued for the next level; a short one is
+// sorted through by its wave alone (wave_lvl_sort with the loop's remaining depth limit) and marked every 16 elements.  Segments
+// are disjoint and std::sort treats them independently, so the permutation is std::sort's whatever the dealing.
+// ALL NW waves call this with the same arguments (workgroup barriers inside).  Returns false when a short segment met the
+// depth limit (the array is partly sorted: the caller starts over from the original order with a form that follows std::sort
+// into its heap sort).  segq: two queues of QCAP segments (first, last, depth); qcnt[3]: the queues' lengths and the failure flag;
+// tab / tab2: NW tables of 64*LREG entries.
+// ---------------------------------------------------------------------------
+template <class T, class Less, int NW, int LREG>
+__device__ bool block_std_sort_lvl(T* a, const int n, Less less, uint16_t* ulist, uint16_t* dlist, uint32_t* segmark, int32_t* segq, int32_t* qcnt, const int QCAP,
+                                   uint32_t* tab, uint16_t* tab2, const int wave, const int lane) {
+    constexpr int NTB = NW * 64;
+    const int tid = wave * 64 + lane;
+    const uint64_t lt = lanemask_lt(lane);
+    for (int q = tid; q < (n + 31) / 32 + 1; q += NTB) segmark[q] = 0u;
+    if (tid == 0) {
+        int depth0 = 0;
+        for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+        qcnt[0] = n > 16 ? 1 : 0; qcnt[1] = 0; qcnt[2] = 0;
+        segq[0] = 0; segq[1] = n; segq[2] = 2 * depth0;
+    }
+    __syncthreads();
+    if (n < 2) return true;
+    if (n <= 16) {
+        if (tid == 0) gs_insertion_sort<T>(a, n, less);
+        __syncthreads();
+        return true;
+    }
+    uint32_t* const mytab = tab + wave * 64 * LREG;
+    uint16_t* const mytab2 = tab2 + wave * 64 * LREG;
+    int cur = 0;
+    while (true) {
+        const int ncur = qcnt[cur];
+        if (ncur == 0) break;
+        int32_t* const qin = segq + cur * 3 * QCAP;
+        int32_t* const qout = segq + (cur ^ 1) * 3 * QCAP;
+        for (int sidx = wave; sidx < ncur; sidx += NW) {
+            const int first = qin[3 * sidx], last = qin[3 * sidx + 1];
+            int depth = qin[3 * sidx + 2];
+            if (last - first <= 64 * LREG) {
+                if (!wave_lvl_sort<T, Less, LREG>(a + first, last - first, less, ulist + first, dlist + first, mytab, mytab2, lane, depth)) { if (lane == 0) qcnt[2] = 1; }
+                for (int q = first + 16 * lane; q < last; q += 16 * 64) atomicOr(&segmark[q >> 5], 1u << (q & 31));
+                WAVE_SYNC();
+                continue;
+            }
+            if (depth == 0) {
+                if (lane == 0) { gs_heap_sort<T>(a, first, last, less); atomicOr(&segmark[first >> 5], 1u << (first & 31)); }
+                WAVE_SYNC();
+                continue;
+            }
+            --depth;
+            if (lane == 0) {   // __move_median_to_first(first, first+1, mid, last-1)
+                int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+                int pick;
+                if (less(a[ia], a[ib])) {
+                    if (less(a[ib], a[ic])) pick = ib;
+                    else if (less(a[ia], a[ic])) pick = ic;
+                    else pick = ia;
+                } else if (less(a[ia], a[ic])) pick = ia;
+                else if (less(a[ib], a[ic])) pick = ic;
+                else pick = ib;
+                T t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            WAVE_SYNC();
+            const T pv = a[first];
+            uint16_t* const ul = ulist + first;
+            uint16_t* const dl = dlist + first;
+            int nu = 0, nd = 0;
+            for (int p0 = first + 1; p0 < last; p0 += 64) {
+                int p = p0 + lane;
+                bool stop = (p < last) && !less(a[p], pv);
+                uint64_t mk = __ballot(stop);
+                if (stop) ul[nu + popc64(mk & lt)] = (uint16_t)p;
+                nu += popc64(mk);
+            }
+            for (int p0 = last - 1; p0 > first; p0 -= 64) {
+                int p = p0 - lane;
+                bool stop = (p > first) && !less(pv, a[p]);
+                uint64_t mk = __ballot(stop);
+                if (stop) dl[nd + popc64(mk & lt)] = (uint16_t)p;
+                nd += popc64(mk);
+            }
+            if (lane == 0) dl[nd] = (uint16_t)first;   // the pivot itself stops the down-scan
+            WAVE_SYNC();
+            int k = 0;
+            {
+                const int tmax = nu < nd ? nu : nd;
+                bool open = true;
+                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
+                    int t = t0 + lane;
+                    bool ok = (t < tmax) && (ul[t] < dl[t]);
+                    uint64_t mk = __ballot(ok);
+                    uint64_t inv = ~mk;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    k += run;
+                    open = (run == 64);
+                }
+            }
+            T xu, xd;
+            for (int t0 = 0; t0 < k; t0 += 64) {
+                int t = t0 + lane;
+                if (t < k) { xu = a[ul[t]]; xd = a[dl[t]]; }
+                WAVE_SYNC();
+                if (t < k) { a[ul[t]] = xd; a[dl[t]] = xu; }
+                WAVE_SYNC();
+            }
+            int cut;
+            {
+                int cu = (k < nu) ? (int)ul[k] : 0x7FFFFFFF;
+                int cd = (k > 0) ? (int)dl[k - 1] : 0x7FFFFFFF;
+                cut = cu < cd ? cu : cd;
+            }
+            WAVE_SYNC();
+            if (lane == 0) {
+                if (cut - first > 16) { const int qi = atomicAdd(&qcnt[cur ^ 1], 1); qout[3 * qi] = first; qout[3 * qi + 1] = cut; qout[3 * qi + 2] = depth; }
+                else atomicOr(&segmark[first >> 5], 1u << (first & 31));
+                if (last - cut > 16) { const int qi = atomicAdd(&qcnt[cur ^ 1], 1); qout[3 * qi] = cut; qout[3 * qi + 1] = last; qout[3 * qi + 2] = depth; }
+                else if (cut < last) atomicOr(&segmark[cut >> 5], 1u << (cut & 31));
+            }
+            WAVE_SYNC();
+        }
+        __syncthreads();
+        if (tid == 0) qcnt[cur] = 0;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const bool ok = qcnt[2] == 0;
+    // final insertion sort: thread t takes the segments that start in the 32-position words t, t+NTB, ...
+    if (ok) for (int w0 = tid; w0 * 32 < n; w0 += NTB) {
+        uint32_t bits = segmark[w0];
+        while (bits) {
+            const int s0 = w0 * 32 + __builtin_ctz(bits);
+            bits &= bits - 1;
+            int e0 = n;
+            if (bits) e0 = w0 * 32 + __builtin_ctz(bits);
+            else {
+                for (int w1 = w0 + 1; w1 * 32 < n; ++w1) { uint32_t bb = segmark[w1]; if (bb) { e0 = w1 * 32 + __builtin_ctz(bb); break; } }
+            }
+            if (e0 > n) e0 = n;
+            for (int i = s0 + 1; i < e0; ++i) {
+                T v = a[i];
+                int j = i - 1;
+                while (j >= s0 && less(v, a[j])) { a[j + 1] = a[j]; --j; }
+                a[j + 1] = v;
+            }
+        }
+    }
+    __syncthreads();
+    return ok;
+}
+
+// ---------------------------------------------------------------------------
 // The same restatement for n <= 64 with ONE ELEMENT PER LANE (key and source index in registers):
 // partitions exchange elements with ds_bpermute instead of LDS round trips, the two stop lists are
 // rank-indexed lane ids in a 2 x 66 int LDS scratch, the segment marks are one 64-bit mask and the

@@ -75,7 +75,7 @@ def test_flow_long_column_sorts_match_libstdcxx(ops):
     keys = torch.from_numpy(np.concatenate(arrays)).cuda()
     offs_t = torch.from_numpy(offs).cuda()
     lib, h = ops._handle(torch.device("cuda", 0))
-    for desc in (32, 33, 96, 97):   # bit 5: the dataflow kernel's sort; bit 0: descending; bit 6: records in global memory
+    for desc in (32, 33, 96, 97, 160, 161):   # bit 5: the dataflow kernel's sort; bit 0: descending; bit 6: records in global memory; bit 7: index sort in LDS
         out = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device="cuda")
         assert lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr()) == 0
         got = out.cpu().numpy()
