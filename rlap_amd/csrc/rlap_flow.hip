@@ -273,7 +273,7 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC, NW>& B, int cnt, int lane)
 // Does an id repeat among B.a_nbr[0 .. len0)?  An open-addressing set in the LDS the first sort is about to use (1 yes, 0 no,
 // -1 the column is too long for the set).  Exact: the answer decides whether the list order has to be restored.
 template <class BUF>
-__device__ __forceinline__ int flow_has_dup(BUF& B, int len0, int lane) {
+__device__ __forceinline__ int flow_has_dup(BUF& B, int len0, int lane, int* distinct) {
     int32_t* tab; int cap;
     if constexpr (BUF::SMALL) { tab = reinterpret_cast<int32_t*>(B.rec); cap = (int)(sizeof(B.rec) / 4); }
     else { tab = reinterpret_cast<int32_t*>(B.S->rec); cap = (int)(sizeof(B.S->rec) / 4); }   // (the records' part of the sort overlay)
@@ -284,16 +284,19 @@ __device__ __forceinline__ int flow_has_dup(BUF& B, int len0, int lane) {
     for (int q = lane; q < size; q += 64) tab[q] = -1;
     WAVE_SYNC();
     bool dup = false;
+    int nnew = 0;
     for (int i = lane; i < len0; i += 64) {
         const int32_t id = B.a_nbr[i];
         uint32_t hpos = ((uint32_t)id * 2654435761u) >> (32 - bits);
         while (true) {
             const int32_t old = atomicCAS(&tab[hpos], -1, id);
-            if (old == -1) break;
+            if (old == -1) { ++nnew; break; }
             if (old == id) { dup = true; break; }
             hpos = (hpos + 1) & (uint32_t)mask;
         }
     }
+    for (int off = 32; off > 0; off >>= 1) nnew += __shfl_xor(nnew, off);
+    *distinct = nnew;   // = the neighbours left after the merge (:646-659)
     const bool any = __ballot(dup) != 0ull;
     WAVE_SYNC();
     return any ? 1 : 0;
@@ -464,11 +467,20 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     WAVE_SYNC();
     FSTAMP(1);
 
+    bool published = false;
     // ---- sort by neighbour id (std::sort semantics, :641-644).  Where ids repeat, the list order is part of the result: the appended
     //      entries are first put newest first (descending tag).  Whether they repeat is asked of a hash set, not of a sort ----
     {
         bool need_tag = false, sorted = false;
-        const int dupk = napp > 1 ? flow_has_dup(B, len0, lane) : 0;
+        int distinct = -1;
+        const int dupk = (napp > 1 || !BUF::SMALL) ? flow_has_dup(B, len0, lane, &distinct) : 0;
+        if constexpr (!BUF::SMALL) {
+            // a long column holds the look-back front for as long as its count is unknown: the set has it before any sort
+            if (dupk >= 0 && distinct >= 0) {
+                published = true;
+                if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)(distinct > 1 ? distinct - 1 : 0));
+            }
+        }
         if (dupk < 0) {   // (too long for the set: sort, look, and sort again if need be)
             for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
             WAVE_SYNC();
@@ -519,7 +531,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         m += popc64(mask); nk += popc64(kmask);
     }
     const int32_t cdraw = m > 1 ? m - 1 : 0;
-    if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)cdraw);   // my count: later positions can look past me now
+    if (lane == 0 && !published) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)cdraw);   // my count: later positions can look past me now
     WAVE_SYNC();
     FSTAMP(3);
     FLOW_JITTER(1);
