@@ -35,8 +35,9 @@ constexpr int32_t FPOS_NONE = 0x7FFFFFFF;  // VRec::pqpos of a vertex that is no
 // look-back word of a position: bit 63 = count published, bit 62 = the value is the INCLUSIVE prefix (else the position's own count)
 constexpr unsigned long long LB_VALID = 1ull << 63, LB_PREFIX = 1ull << 62, LB_MASK = (1ull << 62) - 1ull;
 
-// control words (index into FlowArrays::ctrl): next claim, abort status, long-column scratch top (entries), long columns met, committed positions
-enum { FC_CLAIM = 0, FC_ABORT = 32, FC_SCR = 64, FC_LONG = 96, FC_PROGRESS = 128, FC_WORDS = 160 };
+// control words (index into FlowArrays::ctrl): next claim, abort status, long-column scratch top (entries), long columns met, committed positions,
+// very long columns being worked on (no stall is declared meanwhile)
+enum { FC_CLAIM = 0, FC_ABORT = 32, FC_SCR = 64, FC_LONG = 96, FC_PROGRESS = 128, FC_HEAVY = 160, FC_WORDS = 192 };
 
 struct FlowArrays {
     int32_t* cdir;              // [N * FDIR]

@@ -311,7 +311,7 @@ struct FlowWatch { int32_t seen; long long t0; };
 __device__ __forceinline__ bool flow_stalled(const FlowArrays& F, const FlowParams& P, FlowWatch& w) {
     const int32_t now_p = ag_ld(&F.ctrl[FC_PROGRESS]);
     const long long now_t = wall_clock64();
-    if (now_p != w.seen) { w.seen = now_p; w.t0 = now_t; return false; }
+    if (now_p != w.seen || ag_ld(&F.ctrl[FC_HEAVY]) > 0) { w.seen = now_p; w.t0 = now_t; return false; }   // (a hub of 10^5 entries takes one wave seconds: that is work, not a stall)
     return now_t - w.t0 > (long long)P.spin_limit * 100000ll;   // spin_limit: milliseconds
 }
 
@@ -792,7 +792,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
             Gb.X = reinterpret_cast<FlowIdxLds<EC, NW>*>(&L);
             Gb.stk = L.stk; Gb.tmp = L.tmp;
             Gb.kind = !FLOW_BIG_IN_LDS ? 0 : (ext <= FlowSortLds<EC, NW>::BIGL ? 1 : (ext <= FlowIdxLds<EC, NW>::IDXL ? 2 : 0));
+            const bool heavy = ext > 16384;
+            if (heavy && lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_HEAVY], 1, RLX, AGT);
             ok = flow_eliminate<NW>(s_cmd, ON, A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+            if (heavy && lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_HEAVY], -1, RLX, AGT);
             if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_LONG], 1, RLX, AGT);
         }
         if (!ok) break;

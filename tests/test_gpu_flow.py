@@ -123,6 +123,11 @@ def test_flow_long_columns_and_hubs(ops, flow_env):
     perm = np.concatenate([1 + rng.permutation(4999), [0]])   # the centre is popped first: one 4999-entry column
     check(ops, ei, None, 5000, 2500, "asc", perm, "star5000")
     check(ops, ei, sym_weights(ei, 5000, 2), 5000, 2500, "desc", perm, "star5000 w")
+    # beyond the 16-bit stop lists of the wave sorts (65,000 entries): one lane sorts, the others must not call it a stall
+    n = 70001
+    ei = star(n)
+    perm = np.concatenate([1 + rng.permutation(n - 1), [0]])
+    check(ops, ei, None, n, 300, "asc", perm, "star70001")
 
 
 def test_flow_equals_round_kernel_on_a_medium_graph(ops, flow_env):
