@@ -77,6 +77,13 @@ int rlap_create(rlap_handle* out);
 int rlap_destroy(rlap_handle h);
 int rlap_set_stream(rlap_handle h, void* hip_stream); /* hipStream_t; NULL = default */
 
+/* Where the sampling uniforms come from (SURVEY section 7 step 7 / 8(b) `mode`).  0 = "exact" (default): the first outputs of
+ * the default-seeded std::mt19937_64 in elimination order, preconditioner.cc:356-357,386 -- results equal the reference's.
+ * 1 = "frontier": the j-th uniform of a vertex's elimination is a function of (seed, vertex, j); same distribution, no order
+ * in which draws must be made (for o_v = random the multi-CU kernel then waits for nothing but its true neighbours);
+ * bit-exact against the oracle in the same mode, NOT against the reference.  Applies to the handle's later calls. */
+int rlap_set_rng_mode(rlap_handle h, int mode);
+
 /* Workspace contract (SURVEY 8(b) "caller owns every buffer"; the reference's only allocation is the torch tensor of its
  * result, py_api_binder.cc:42).
  *   rlap_workspace_bytes : upper bound, for a fresh handle, of the arena bytes and of the uniform-table entries a call on

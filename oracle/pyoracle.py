@@ -56,7 +56,7 @@ def _load():
 
 def approximate_cholesky(edge_index, edge_weights, num_nodes, num_remove, o_v, o_n, *, perm=None,
                          shuffle_seed=0, sort="libstdcxx", faithful=True, return_order=False,
-                         return_stats=False):
+                         return_stats=False, mode="exact"):
     """Oracle with the reference's signature (rlap/ops.py:7-14) on numpy arrays.
 
     edge_index (2,E) integer, edge_weights (1,E)/(E,)/None. Returns (m,3) float64.
@@ -82,7 +82,7 @@ def approximate_cholesky(edge_index, edge_weights, num_nodes, num_remove, o_v, o
     rc = lib.rlap_oracle_approx_chol(
         info.ctypes.data, E, int(num_nodes), int(num_remove), O_V[o_v], O_N[o_n],
         perm_arr.ctypes.data if perm_arr is not None else None, int(shuffle_seed) & (2**64 - 1),
-        0 if sort == "libstdcxx" else 1, 1 if faithful else 0,
+        (0 if sort == "libstdcxx" else 1) | (16 if mode == "frontier" else 0), 1 if faithful else 0,
         ctypes.byref(out), ctypes.byref(rows), order.ctypes.data, ctypes.byref(st))
     if rc == 1:
         raise ValueError("adjacency matrix is not symmetric")

@@ -381,6 +381,20 @@ struct Out {
 
 inline double draw(std::mt19937_64& g, std::uniform_real_distribution<double>& d) { return d(g); }
 
+// mode "frontier" (no counterpart in the reference): the j-th uniform of the elimination of
+// `vertex` is a function of (seed, vertex, j), not the next output of the one stream.  Same definition as
+// rlap_amd/csrc/rlap_core.h::frontier_uniform (restated here: the oracle shares no code with the product).
+inline uint64_t fr_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline double oracle_frontier_uniform(uint64_t seed, int64_t vertex, int64_t j) {
+    const uint64_t z = fr_mix64(fr_mix64((seed ^ 0x66726F6E74696572ull) ^ fr_mix64((uint64_t)vertex)) ^ fr_mix64((uint64_t)j));
+    return (double)(z >> 11) * 1.1102230246251565e-16;   // 2^-53
+}
+
 // :377-418 / :740-776 : the sampled star -> tree rewrite, shared by degree/random
 inline void rewire(Lists* L, Node* ll, double j, double k, double w) {
     Node* rv = ll->twin;
@@ -421,6 +435,8 @@ int rlap_oracle_approx_chol(const double* edge_info, int64_t E, int64_t n, int64
     if (rc) return rc;
     rc = check_symmetric(A, faithful != 0);
     if (rc) return rc;
+    const bool counter_rng = (sort_mode & 16) != 0;   // bit 4 of sort_mode: mode "frontier"
+    sort_mode &= 15;
     Ctx cx{o_v == 2 ? 2 : o_n, sort_mode, shuffle_seed};  // coarsen forces "random" (:830-831)
     Lists* L = build_lists(A);
     DegPq* pq = (o_v != 0) ? pq_build(L->degs) : nullptr;
@@ -450,7 +466,7 @@ int rlap_oracle_approx_chol(const double* edge_info, int64_t E, int64_t n, int64
             double csum = 0;
             cum.clear(); vals.clear();
             for (int64_t a = 0; a < len; ++a) { vals.push_back(cs[a]->val); csum += cs[a]->val; cum.push_back(csum); }
-            double u = draw(gen, ud); ++ndraw;
+            double u = counter_rng ? oracle_frontier_uniform(shuffle_seed, i, 0) : draw(gen, ud); ++ndraw;
             double r = u * csum;
             int64_t koff = len - 1;
             for (int64_t a = 0; a < len; ++a) if (cum[a] > r) { koff = a; break; }
@@ -477,7 +493,7 @@ int rlap_oracle_approx_chol(const double* edge_info, int64_t E, int64_t n, int64
             double w = vals[jo] * colScale;
             double j = ll->row;
             double f = w / wdeg;
-            double u = draw(gen, ud); ++ndraw;
+            double u = counter_rng ? oracle_frontier_uniform(shuffle_seed, i, jo) : draw(gen, ud); ++ndraw;
             double r = u * (csum - cum[jo]) + cum[jo];
             int64_t koff = len - 1;
             for (int64_t a = 0; a < len; ++a) if (cum[a] > r) { koff = a; break; }

@@ -18,6 +18,7 @@ EXPORTS = [
     "rlap_rng_uniforms", "rlap_util_ba_graph", "rlap_debug_wave_sort",
     "rlap_approx_chol_from_edges", "rlap_debug_set_limits", "rlap_pack_rows", "rlap_unpack_rows",
     "rlap_workspace_bytes", "rlap_workspace_query", "rlap_set_workspace", "rlap_workspace_needed", "rlap_debug_set_poison", "rlap_debug_set_jitter",
+    "rlap_set_rng_mode",
 ]
 
 E_WORKSPACE = 11   # RLAP_E_WORKSPACE
@@ -79,6 +80,8 @@ def load():
     lib.rlap_unpack_rows.argtypes = [vp, vp, i64, vp]
     lib.rlap_rng_uniforms.restype = ci
     lib.rlap_rng_uniforms.argtypes = [vp, i64, vp]
+    lib.rlap_set_rng_mode.restype = ci
+    lib.rlap_set_rng_mode.argtypes = [vp, ci]
     lib.rlap_debug_wave_sort.restype = ci
     lib.rlap_debug_wave_sort.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, vp]
     sz = ctypes.c_size_t

@@ -90,6 +90,7 @@ struct rlap_handle_s {
     int64_t scr_budget = 1 << 18; // output pass: entries of global scratch for columns beyond 8192 slots
     double flow_scr_factor = 1.0; // dataflow elimination: working storage of the long columns (grown after ST_FLOW_SCRATCH)
     bool flow_off_once = false;   // the next attempt uses the round kernel (set after ST_FLOW_REORDER)
+    int rng_mode = 0;             // 0 the reference's one stream (mode "exact"), 1 counter-based uniforms (mode "frontier", rlap_set_rng_mode)
     // test hooks (rlap_debug_set_limits): tiny first sizes so that the retry path runs
     double dbg_pool = -1.0, dbg_log = -1.0; int64_t dbg_rng = -1, dbg_scr = -1;
     int64_t total_retries = 0;
@@ -541,6 +542,8 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     A.bs_pool_top = W.bs_pool_top.as<int32_t>(); A.bs_pool_cap = (int32_t)log_total;
     A.rng = h->rng_ptr; A.rng_len = rng_len_eff;
     A.perm = d_perm; A.o_v = c.o_v; A.o_n = c.o_n; A.shuffle_seed = c.seed;
+    A.rng_mode = h->rng_mode ? RNG_COUNTER : RNG_STREAM; A.vbase = 0;
+    if (A.rng_mode == RNG_COUNTER) A.rng_len = (int64_t)1 << 62;   // (no table is read: the stream-length checks of the kernels never fire)
     ElimScratch ES;
     ES.rec = W.scr_rec.as<SRec>(); ES.i32 = W.scr_i32.as<int32_t>(); ES.f64 = W.scr_f64.as<double>(); ES.cap = scr_total;
     ES.eqtab = h->eqtab.as<uint8_t>();
@@ -850,6 +853,13 @@ int rlap_workspace_needed(rlap_handle h, size_t* ws_bytes, int64_t* rng_entries)
 int rlap_set_stream(rlap_handle h, void* hip_stream) {
     if (!h) return RLAP_E_BAD_ARG;
     h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return RLAP_OK;
+}
+
+int rlap_set_rng_mode(rlap_handle h, int mode) {
+    if (!h || (mode != 0 && mode != 1)) return RLAP_E_BAD_ARG;
+    std::lock_guard<std::mutex> lock(h->mu);
+    h->rng_mode = mode;
     return RLAP_OK;
 }
 

@@ -60,6 +60,18 @@ RLAP_HD uint64_t keyed_order_base(uint64_t seed, int64_t vertex, int phase) {
 RLAP_HD uint64_t keyed_order_key(uint64_t base, int64_t nbr) { return mix64(base ^ mix64((uint64_t)nbr)); }
 
 // ---------------------------------------------------------------------------
+// mode = "frontier" (SURVEY section 7 step 7, H2): the j-th uniform an elimination of `vertex` draws is a function of
+// (seed, vertex, j) instead of the next output of the ONE MT19937-64 stream the reference consumes in elimination order
+// (preconditioner.cc:356-357).  Same distribution, no order in which the draws must be made; bit-exact against the oracle run
+// in the same mode, NOT against the reference.  53 random bits -> [0, 1).  Ids are LOCAL to the graph, the seed is the graph's.
+// ---------------------------------------------------------------------------
+enum { RNG_STREAM = 0, RNG_COUNTER = 1 };
+RLAP_HD double frontier_uniform(uint64_t seed, int64_t vertex, int64_t j) {
+    const uint64_t z = mix64(mix64((seed ^ 0x66726F6E74696572ull) ^ mix64((uint64_t)vertex)) ^ mix64((uint64_t)j));
+    return (double)(z >> 11) * 1.1102230246251565e-16;   // 2^-53
+}
+
+// ---------------------------------------------------------------------------
 // Appended-entry chunks.  Column v = CSR segment [colptr[v], colptr[v+1]) plus
 // `app_cnt[v]` appended entries kept in geometrically growing chunks:
 // chunk c holds appended indices [CHUNK0*(2^c-1), CHUNK0*(2^(c+1)-1)).
@@ -352,7 +364,13 @@ struct Arrays {
     const int64_t* perm;     // [N] local ids (o_v random), graph g at [vbase, vbase+n)
     int32_t o_v; int32_t o_n;
     uint64_t shuffle_seed;
+    int32_t rng_mode;        // RNG_STREAM: uniforms from `rng` in elimination order (the reference); RNG_COUNTER: frontier_uniform(shuffle_seed, vertex, j)
+    int32_t vbase;           // global id of the graph's local vertex 0 (the kernels set it per graph)
 };
+// the j-th uniform of the elimination of `vertex` (global id), draw number `draw` of the graph's stream
+RLAP_HD double arr_uniform(const Arrays& A, int64_t draw, int32_t vertex, int32_t j) {
+    return A.rng_mode == RNG_COUNTER ? frontier_uniform(A.shuffle_seed, (int64_t)(vertex - A.vbase), (int64_t)j) : A.rng[draw];
+}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 RLAP_HD int32_t pool_take(int32_t* top, int32_t cnt) { return atomicAdd(top, cnt); }
@@ -564,8 +582,8 @@ RLAP_HD int serial_eliminate(const Arrays& A, GraphDesc& G, const ColBuf& B, int
         if (m >= 1) {
             double csum = 0;
             for (int32_t j = 0; j < m; ++j) { csum += B.a_val[j]; B.cum[j] = csum; }
-            if (G.n_draws >= A.rng_len) return ST_RNG_OVERFLOW;
-            double u = A.rng[G.n_draws]; G.n_draws += 1;
+            if (A.rng_mode != RNG_COUNTER && G.n_draws >= A.rng_len) return ST_RNG_OVERFLOW;
+            double u = arr_uniform(A, G.n_draws, v, 0); G.n_draws += 1;
             double r = u * csum;
             int32_t koff = upper_index(B.cum, m, r);
             int32_t k = B.a_nbr[koff];
@@ -585,12 +603,12 @@ RLAP_HD int serial_eliminate(const Arrays& A, GraphDesc& G, const ColBuf& B, int
     } else {
         double csum = 0;
         for (int32_t j = 0; j < m; ++j) { csum += B.a_val[j]; B.cum[j] = csum; }
-        if (m > 1 && G.n_draws + (m - 1) > A.rng_len) return ST_RNG_OVERFLOW;
+        if (A.rng_mode != RNG_COUNTER && m > 1 && G.n_draws + (m - 1) > A.rng_len) return ST_RNG_OVERFLOW;
         double wdeg = csum, colScale = 1;
         for (int32_t j = 0; j < m - 1; ++j) {
             double w = B.a_val[j] * colScale;
             double f = w / wdeg;
-            double u = A.rng[G.n_draws + j];
+            double u = arr_uniform(A, G.n_draws + j, v, j);
             double r = u * (csum - B.cum[j]) + B.cum[j];
             int32_t koff = upper_index(B.cum, m, r);
             B.ksel[j] = koff;
@@ -873,7 +891,7 @@ RLAP_HD void cand_cumsum(const Arrays& A, CT& C) {
     double csum = 0;
     for (int32_t j = 0; j < m; ++j) { csum += C.e[j].val; C.e[j].aux = csum; }
     if (A.o_v == OV_COARSEN && m >= 1) {
-        double u = A.rng[C.draw0];
+        double u = arr_uniform(A, C.draw0, C.v, 0);
         double r = u * csum;
         int32_t koff = ent_upper_index(C.e, m, r);
         C.koff = koff;
@@ -891,7 +909,7 @@ template <class CT>
 RLAP_HD void cand_pick(const Arrays& A, CT& C, int32_t j) {
     const int32_t m = C.m;
     double csum = C.e[m - 1].aux;
-    double u = A.rng[C.draw0 + j];
+    double u = arr_uniform(A, C.draw0 + j, C.v, j);
     double cj = C.e[j].aux;
     double r = u * (csum - cj) + cj;
     C.ksel[j] = (uint8_t)ent_upper_index(C.e, m, r);

@@ -142,9 +142,17 @@ struct FlowIdxLds {
 struct IdxKeyLess { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { return key[a] < key[b]; } };
 struct IdxKeyGreater { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { return key[a] > key[b]; } };
 enum { FCMD_SORT = 1, FCMD_EXIT = 2, FCMD_RECUR = 3 };
-template <int EC, int NW>
+// The elimination kernel's long columns are sorted by the owning wave alone (MW = false): with the multi-wave sort called from
+// that kernel, LDS reads through addresses the compiler derives (ds_read) returned other data than flat loads of the same
+// generic address issued beside them, in a build-dependent number of lanes -- see DESIGN.md 8.4 (not root-caused; the sort
+// itself is exact, tests/test_gpu_flow.py drives it through k_debug_flow_sort with MW = true).  The helper wave keeps the recurrence.
+#ifndef RLAP_FLOW_MW_SORT
+#define RLAP_FLOW_MW_SORT 0
+#endif
+template <int EC, int NW, bool MW = false>
 struct FlowBig {
     static constexpr bool SMALL = false;
+    static constexpr bool MWSORT = MW;
     FlowSortLds<EC, NW>* S;  // derived from the kernel's __shared__ block (the compiler sees LDS addresses)
     FlowIdxLds<EC, NW>* X;   // the same block, index-sort view
     int32_t* stk; int32_t* tmp;
@@ -211,8 +219,8 @@ __device__ __forceinline__ void flow_sort(FlowLds<EC>& B, int cnt, int lane) {
     }
     WAVE_SYNC();
 }
-template <bool GREATER, int EC, int NW>
-__device__ __forceinline__ void flow_sort(FlowBig<EC, NW>& B, int cnt, int lane) {
+template <bool GREATER, int EC, int NW, bool MW>
+__device__ __forceinline__ void flow_sort(FlowBig<EC, NW, MW>& B, int cnt, int lane) {
     typedef typename std::conditional<GREATER, SRecGreaterKey, SRecLessKey>::type Cmp;
     typedef typename std::conditional<GREATER, IdxKeyGreater, IdxKeyLess>::type ICmp;
     constexpr int LVL = FlowSortLds<EC, NW>::LVL;
@@ -226,7 +234,7 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC, NW>& B, int cnt, int lane)
         };
         stage();
         bool ok = false;
-        if constexpr (NW > 1 && LVL > 0) {
+        if constexpr (MW && NW > 1 && LVL > 0) {
             if (cnt > LVL) {   // worth the helpers: partitions level by level over the workgroup's waves, the level-synchronous form per short segment
                 if (lane == 0) { B.cmd[1] = B.kind; B.cmd[2] = cnt; B.cmd[3] = GREATER ? 1 : 0; B.cmd[0] = FCMD_SORT; }
                 __syncthreads();
@@ -239,7 +247,7 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC, NW>& B, int cnt, int lane)
         if (B.kind == 1) {
             const WaveSortPtrs WP = {S.ulist, S.dlist, S.segmark, B.stk};
             if constexpr (LVL > 0) {
-                if (!ok && !(NW > 1 && cnt > LVL)) {
+                if (!ok && !(MW && NW > 1 && cnt > LVL)) {
                     ok = wave_std_sort_hyb<SRec, Cmp, LVL / 64>(S.rec, cnt, Cmp(), WP, S.tab, S.tab2, lane);
                     if (!ok) stage();
                 }
@@ -249,7 +257,7 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC, NW>& B, int cnt, int lane)
             const ICmp less{X.key};
             const WaveSortPtrs WP = {X.ulist, X.dlist, X.segmark, B.stk};
             if constexpr (LVL > 0) {
-                if (!ok && !(NW > 1 && cnt > LVL)) {
+                if (!ok && !(MW && NW > 1 && cnt > LVL)) {
                     ok = wave_std_sort_hyb<uint16_t, ICmp, LVL / 64>(X.idx, cnt, less, WP, X.tab, X.tab2, lane);
                     if (!ok) stage();
                 }
@@ -447,10 +455,11 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
             const bool live = valid && val > 0;
             const uint64_t mask = __ballot(live);
             const int pos = len0 + popc64(mask & lt);
-            if (live && pos < cap) { B.a_nbr[pos] = nb; B.a_val[pos] = val; B.a_twin[pos] = tw; B.a_tag[pos] = tg; }
+            if (live && pos < cap) { B.a_nbr[pos] = nb; B.a_val[pos] = val; B.a_twin[pos] = tw; B.a_tag[pos] = tg; B.b_dup[pos] = i; }   // (b_dup: the appended index, until the merge)
             len0 += popc64(mask);
         }
         napp = len0;
+        if (acnt > (1 << 22)) { flow_fail(F, ST_INTERNAL); return false; }   // (the list-order key below holds 22 bits of appended index)
         for (int32_t s0 = cp1 - 1; s0 >= cp0; s0 -= 64) {
             const int32_t s = s0 - lane;
             const bool valid = s >= cp0;
@@ -476,7 +485,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         const int dupk = (napp > 1 || !BUF::SMALL) ? flow_has_dup(B, len0, lane, &distinct) : 0;
         if constexpr (!BUF::SMALL) {
             // a long column holds the look-back front for as long as its count is unknown: the set has it before any sort
-            if (dupk >= 0 && distinct >= 0) {
+            if (dupk >= 0 && distinct >= 0 && A.rng_mode != RNG_COUNTER) {
                 published = true;
                 if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)(distinct > 1 ? distinct - 1 : 0));
             }
@@ -491,7 +500,8 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
             need_tag = __ballot(dup) != 0ull;
         } else need_tag = dupk > 0;
         if (need_tag) {
-            for (int i = lane; i < napp; i += 64) B.skey[i] = -(double)B.a_tag[i];
+            // newest first: by the tag, then -- entries one elimination pushed into this column share a tag in mode "frontier" -- by the appended index
+            for (int i = lane; i < napp; i += 64) B.skey[i] = -((double)B.a_tag[i] * 4194304.0 + (double)B.b_dup[i]);
             WAVE_SYNC();
             flow_sort<false>(B, napp, lane);   // distinct keys
             for (int i = lane; i < napp; i += 64) { const int s = B.R(i).idx; B.b_nbr[i] = B.a_nbr[s]; B.b_twin[i] = B.a_twin[s]; B.b_val[i] = B.a_val[s]; }
@@ -531,7 +541,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         m += popc64(mask); nk += popc64(kmask);
     }
     const int32_t cdraw = m > 1 ? m - 1 : 0;
-    if (lane == 0 && !published) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)cdraw);   // my count: later positions can look past me now
+    if (lane == 0 && !published && A.rng_mode != RNG_COUNTER) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)cdraw);   // my count: later positions can look past me now
     WAVE_SYNC();
     FSTAMP(3);
     FLOW_JITTER(1);
@@ -588,7 +598,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     FSTAMP(5);
     // ---- uniform offset: decoupled look-back over the published counts (the stream is consumed in order, :729) ----
     long long D = 0;
-    {
+    if (A.rng_mode != RNG_COUNTER) {
         long long sum = 0;
         int32_t hi = idx - 1;   // highest position not yet added
         int spins = 0;
@@ -617,16 +627,21 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         }
         D = sum;
     }
-    if (D + cdraw > A.rng_len) { flow_fail(F, ST_RNG_OVERFLOW); if (helped) __syncthreads(); return false; }
-    if (lane == 0) ag_st64(F.lb + idx, LB_VALID | LB_PREFIX | (unsigned long long)(D + cdraw));
-    *last_draws = (int32_t)(D + cdraw);
+    if (A.rng_mode != RNG_COUNTER) {
+        if (D + cdraw > A.rng_len) { flow_fail(F, ST_RNG_OVERFLOW); if (helped) __syncthreads(); return false; }
+        if (lane == 0) ag_st64(F.lb + idx, LB_VALID | LB_PREFIX | (unsigned long long)(D + cdraw));
+        *last_draws = (int32_t)(D + cdraw);
+    } else {   // mode "frontier": no stream, no offsets, nobody to wait for -- the draws are only counted
+        if (lane == 0 && cdraw > 0) atomicAdd(reinterpret_cast<unsigned long long*>(&P.gd[g].n_draws), (unsigned long long)cdraw);
+        *last_draws = -1;
+    }
     FSTAMP(6);
     FLOW_JITTER(2);
 
     // ---- sample k for every position but the last (:747-756) ----
     const double csum = m > 0 ? cum[m - 1] : 0.0;
     for (int j = lane; j < m - 1; j += 64) {
-        const double u = A.rng[D + j];
+        const double u = (A.rng_mode == RNG_COUNTER) ? frontier_uniform(gseed, (int64_t)(v - vbase), (int64_t)j) : A.rng[D + j];
         const double cj = cum[j];
         const double r = u * (csum - cj) + cj;
         B.ksel[j] = upper_index(cum, m, r);
@@ -648,15 +663,32 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
             const int32_t ks = B.ksel[j];
             k = B.a_nbr[ks]; pk = B.f_pos[ks];
             a = B.a_nbr[j]; pa = B.f_pos[j]; s_r = B.a_twin[j]; nw = newv[j];
-            ai = ag_add(&A.vr[k].app_cnt, 1);
-            c = chunk_of(ai);
+        }
+        {   // lanes that drew the same target form a group: ONE returning atomic per group, its indices handed out in lane (= position)
+            // order -- what one elimination pushes into a column is then in list order among itself
+            uint64_t todo = __ballot(act), mymask = 0ull;
+            while (todo) {
+                const int ld = __builtin_ctzll(todo);
+                const int32_t kl = __shfl(k, ld);
+                const uint64_t same = __ballot(act && k == kl);
+                if (act && k == kl) mymask = same;
+                todo &= ~same;
+            }
+            if (act) {
+                const int leader = __builtin_ctzll(mymask);
+                int32_t base0 = 0;
+                if (lane == leader) base0 = ag_add(&A.vr[k].app_cnt, popc64(mymask));
+                base0 = __shfl(base0, leader);
+                ai = base0 + popc64(mymask & lt);
+                c = chunk_of(ai);
+            }
         }
         FLOW_JITTER(3 + (lane & 3));
         if (act) base = flow_chunk_base(A, F, P, k, c);
         if (act && base >= 0) {
             const int32_t s_n = base + 1 + (ai - chunk_start(c));
             ag_st_slot(M, s_n, nw, a, s_r);
-            ag_st(F.atag + s_n, (int32_t)(D + j));
+            ag_st(F.atag + s_n, (A.rng_mode == RNG_COUNTER) ? idx : (int32_t)(D + j));   // increasing in the sequential order either way
             ag_st_slot(M, s_r, nw, k, s_n);
             if (nw > 0) {
                 if (pk < pa && pa != FPOS_NONE) ag_add(&A.vr[a].key, 1);
@@ -719,7 +751,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
                         const unsigned long long cb = (unsigned long long)(uint32_t)s_cmd[4] | ((unsigned long long)(uint32_t)s_cmd[5] << 32);
                         flow_recur(reinterpret_cast<const double*>(reinterpret_cast<char*>(&L) + s_cmd[2]), reinterpret_cast<double*>(reinterpret_cast<char*>(&L) + s_cmd[3]), s_cmd[1], __longlong_as_double((long long)cb));
                     }
-                } else
+                } else if constexpr (RLAP_FLOW_MW_SORT != 0)
                 flow_block_sort<EC, NW>(reinterpret_cast<FlowSortLds<EC, NW>*>(&L), reinterpret_cast<FlowIdxLds<EC, NW>*>(&L), s_cmd[1], s_cmd[2], s_cmd[3], wave, lane);
                 __syncthreads();
             }
@@ -775,7 +807,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
             b0 = __builtin_amdgcn_readfirstlane(b0);
             if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); break; }
             char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
-            FlowBig<EC, NW> Gb;
+            FlowBig<EC, NW, RLAP_FLOW_MW_SORT != 0> Gb;
             Gb.cmd = s_cmd;
             const int64_t n8 = want;
             double* d = reinterpret_cast<double*>(base);
@@ -800,7 +832,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
         }
         if (!ok) break;
         // the last position of a graph files the graph's draw count
-        if (lane == 0 && (idx + 1 >= F.Q || F.qv[idx + 1] < 0)) P.gd[g].n_draws = draws;
+        if (lane == 0 && draws >= 0 && (idx + 1 >= F.Q || F.qv[idx + 1] < 0)) P.gd[g].n_draws = draws;
     }
     if constexpr (NW > 1) {   // every way out of the loop ends here: the helpers are sent home
         if (lane == 0) s_cmd[0] = FCMD_EXIT;
@@ -887,7 +919,7 @@ __global__ void k_flow_ro_count(Arrays A, FlowArrays F, const uint32_t* __restri
         if (acnt <= 48) {   // short: look (most columns are in order already)
             bool sorted = true;
             int32_t prev = F.atag[flow_slot_plain(A, F, v, 0)];
-            for (int32_t q = 1; q < acnt; ++q) { const int32_t t = F.atag[flow_slot_plain(A, F, v, q)]; sorted &= t > prev; prev = t; }
+            for (int32_t q = 1; q < acnt; ++q) { const int32_t t = F.atag[flow_slot_plain(A, F, v, q)]; sorted &= t >= prev; prev = t; }
             if (sorted) c = 0;
         }
     }
@@ -938,7 +970,7 @@ __global__ __launch_bounds__(64 * FLOW_NW) void k_debug_flow_sort(const double* 
     }
     for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
         const int32_t o = offs[arr], n = offs[arr + 1] - o;
-        FlowBig<FLOW_EC, FLOW_NW> B;
+        FlowBig<FLOW_EC, FLOW_NW, true> B;
         B.S = reinterpret_cast<FlowSortLds<FLOW_EC, FLOW_NW>*>(&L); B.X = reinterpret_cast<FlowIdxLds<FLOW_EC, FLOW_NW>*>(&L); B.stk = L.stk; B.tmp = L.tmp; B.cmd = s_cmd;
         B.kind = (desc & 64) ? 0 : ((desc & 128) ? (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0) : (n <= FlowSortLds<FLOW_EC, FLOW_NW>::BIGL ? 1 : (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0)));
         B.skey = const_cast<double*>(keys) + o;

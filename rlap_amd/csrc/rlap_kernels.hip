@@ -701,7 +701,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
 
     if (coarsen) {
         if (m >= 1) {
-            double u = A.rng[draws0];
+            double u = arr_uniform(A, draws0, v, 0);
             double r = u * csum;
             koff_c = upper_index(cum, m, r);
             wk_c = L.a_val[koff_c];
@@ -709,7 +709,7 @@ __device__ __noinline__ void wave_eliminate(const Arrays& A, GraphDesc& G, ElimL
     } else {
         // ---- sample k for every position but the last (:385-394) ----
         for (int j = lane; j < m - 1; j += 64) {
-            double u = A.rng[draws0 + j];
+            double u = arr_uniform(A, draws0 + j, v, j);
             double cj = cum[j];
             double r = u * (csum - cj) + cj;
             L.ksel[j] = upper_index(cum, m, r);
@@ -1000,7 +1000,7 @@ __device__ __noinline__ bool wave_eliminate_big(const Arrays& A, GraphDesc& G, B
 
     // ---- sample k for every position but the last (:747-756) ----
     for (int j = lane; j < m - 1; j += 64) {
-        double u = A.rng[draws0 + j];
+        double u = arr_uniform(A, draws0 + j, v, j);
         double cj = cum[j];
         double r = u * (csum - cj) + cj;
         B.ksel[j] = upper_index(cum, m, r);
@@ -1161,9 +1161,9 @@ __device__ __noinline__ void cand_order_index_call(const Arrays& A, CT& C) { can
 // the patched candidate.  d's entries live in registers while they are patched and ordered again: by id with a rank count
 // (ids are distinct), by o_n with the half-wave std::sort restatement.  Returns false when d cannot be patched.
 template <int ON, class CT>
-__device__ __noinline__ bool wave_patch(const int32_t o_v, const uint64_t shuffle_seed, const double* __restrict__ rng, CT* cand, int32_t d, int32_t vbase, int32_t* tmp_wave) {
+__device__ __noinline__ bool wave_patch(const int32_t o_v, const uint64_t shuffle_seed, const double* __restrict__ rng, const int32_t rng_mode, CT* cand, int32_t d, int32_t vbase, int32_t* tmp_wave) {
     Arrays A;            // (by value, like cand_prepare_wide: what the sampling helpers read of the argument block; lives in registers)
-    A.o_v = o_v; A.o_n = ON; A.shuffle_seed = shuffle_seed; A.rng = rng;
+    A.o_v = o_v; A.o_n = ON; A.shuffle_seed = shuffle_seed; A.rng = rng; A.rng_mode = rng_mode; A.vbase = vbase;
     static_assert(CT::CAP == 32 || CT::CAP == 64, "one entry per lane");
     const int lane = lane_id();
     CT& C = cand[d];
@@ -1557,6 +1557,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
     A.o_v = OV;
     A.o_n = ON;
     A.shuffle_seed = A_in.shuffle_seed + (uint64_t)blockIdx.x;   // graph g of a batch: seed + g, ids local to the graph (rlap_core.h)
+    A.vbase = gd[blockIdx.x].vbase;
     __shared__ ElimSharedT<BC, NTT> sh;
     __shared__ GraphDesc G;
     __shared__ int32_t s_help[3];      // hand-over between the eliminating wave and its helper (single_helper); [2]: the helper gave up waiting
@@ -2182,7 +2183,7 @@ __global__ __launch_bounds__(NTT, (NTT >= 1024 ? 1 : 4)) void k_eliminate_batch_
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     if (i >= *(volatile int32_t*)&s_pmax) lost = true;     // behind a cut already
                     bool okp = false;
-                    if (!lost) okp = wave_patch<ON>(A.o_v, A.shuffle_seed, A.rng, L.cand, i, G.vbase, ptmp);
+                    if (!lost) okp = wave_patch<ON>(A.o_v, A.shuffle_seed, A.rng, A.rng_mode, L.cand, i, G.vbase, ptmp);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) {
                         if (okp) { atomicOr(&C.flags, CF_PATCHED); s_npatched = 1; }

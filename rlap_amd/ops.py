@@ -98,6 +98,19 @@ def _handle(device: torch.device):
     return lib, hobj.ptr
 
 
+MODES = {"exact": 0, "frontier": 1}
+
+
+def _set_mode(lib, h, mode: str):
+    """`mode` of SURVEY 8(b): "exact" (default) draws the reference's one MT19937-64 stream in elimination order -- results equal
+    the reference's; "frontier" draws counter-based uniforms keyed by (seed, vertex, position): the same distribution, bit-exact
+    against the oracle run in that mode, not against the reference (include/rlap_hip.h::rlap_set_rng_mode)."""
+    assert mode in MODES, f"mode must be one of {sorted(MODES)}"
+    rc = lib.rlap_set_rng_mode(h, MODES[mode])
+    if rc != 0:
+        _raise(rc)
+
+
 def _trim(out: torch.Tensor, rows: int) -> torch.Tensor:
     """The first `rows` rows of the (E,3) result buffer.  A view keeps the whole buffer alive, a copy costs a pass over the
     result (0.6 ms for the 1.5 GB of the 1024-graph batch): copy only when the view would pin more than a third on top."""
@@ -209,6 +222,7 @@ def approximate_cholesky(
     perm: Optional[Tensor] = None,
     seed: Optional[int] = None,
     return_device: Optional[Union[str, torch.device]] = "cpu",
+    mode: str = "exact",
 ) -> Tensor:
     """Randomized Schur complement of the graph Laplacian (reference: rlap/ops.py:7-58).
 
@@ -224,6 +238,7 @@ def approximate_cholesky(
     dev = _device_for(edge_index)
     lib, hobj = _handle_obj(dev)
     h = hobj.ptr
+    _set_mode(lib, h, mode)
     with torch.cuda.device(dev):
         row, col, w, E = _prep_edges(edge_index, edge_weights, dev)
         n = int(num_nodes)
@@ -234,7 +249,7 @@ def approximate_cholesky(
         # perm None: the reference shuffles 0..n-1 with std::random_device (preconditioner.cc:594-596); here the node_id vector is
         # drawn on the device from `seed` by the C ABI's keyed shuffle -- the same draw as approximate_cholesky_from_edges and as
         # graph 0 of approximate_cholesky_batched with that seed (ONE meaning of `seed` in this module)
-        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree") else 0
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree" or mode == "frontier") else 0
         out = torch.empty((max(E, 1), 3), dtype=torch.float64, device=dev)
         rows = ctypes.c_int64(0)
         st = _lib.Stats()
@@ -264,6 +279,7 @@ def approximate_cholesky_from_edges(
     perm: Optional[Tensor] = None,
     seed: Optional[int] = None,
     return_device: Optional[Union[str, torch.device]] = None,
+    mode: str = "exact",
 ) -> Tuple[Tensor, int]:
     """The op with the step before it fused into its COO->CSR kernels:
     `to_undirected` + coalesce (scripts/node_shared.py:326-327) when `symmetrize`, and
@@ -277,6 +293,7 @@ def approximate_cholesky_from_edges(
     dev = _device_for(edge_index)
     lib, hobj = _handle_obj(dev)
     h = hobj.ptr
+    _set_mode(lib, h, mode)
     with torch.cuda.device(dev):
         row, col, w, E = _prep_edges(edge_index, edge_weights, dev)
         n = -1 if num_nodes is None else int(num_nodes)
@@ -287,7 +304,7 @@ def approximate_cholesky_from_edges(
             d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
             assert d_perm.numel() == n
         # (perm None: the node_id vector is drawn on the device from the seed)
-        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree") else 0
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree" or mode == "frontier") else 0
         cap = max((2 * E) if symmetrize else E, 1)
         out = torch.empty((cap, 3), dtype=torch.float64, device=dev)
         rows = ctypes.c_int64(0)
@@ -317,6 +334,7 @@ def approximate_cholesky_batched(
     perm: Optional[Tensor] = None,
     seed: Optional[int] = None,
     return_device: Optional[Union[str, torch.device]] = None,
+    mode: str = "exact",
 ) -> Tuple[Tensor, Tensor]:
     """Batched-graph mode: graph g owns node ids [node_ptr[g], node_ptr[g+1]).
 
@@ -331,6 +349,7 @@ def approximate_cholesky_batched(
     global last_stats
     dev = _device_for(edge_index)
     lib, hobj = _handle_obj(dev)
+    _set_mode(lib, hobj.ptr, mode)
     h = hobj.ptr
     np_ = torch.as_tensor(node_ptr, dtype=torch.int64).cpu().contiguous()
     nr_ = torch.as_tensor(num_remove, dtype=torch.int64).cpu().contiguous()
@@ -345,7 +364,7 @@ def approximate_cholesky_batched(
             if perm is not None:
                 d_perm = perm.to(device=dev, dtype=torch.int64).contiguous()
                 assert d_perm.numel() == N
-        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree") else 0
+        shuffle_seed = _seed_from(seed) if (o_n == "random" or o_v != "degree" or mode == "frontier") else 0
         out = torch.empty((max(E, 1), 3), dtype=torch.float64, device=dev)
         row_ptr = torch.zeros(G + 1, dtype=torch.int64)
         st = _lib.Stats()

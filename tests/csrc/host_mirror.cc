@@ -88,6 +88,7 @@ struct Setup {
         A.bs_cnt = bs_cnt.data(); A.bs_alloc = bs_alloc.data(); A.bs_dir = bs_dir.data(); A.bs_v = bs_v.data(); A.bs_id = bs_id.data();
         A.bs_pool_top = &bs_pool_top; A.bs_pool_cap = bs_pool_cap;
         A.rng = rng.data(); A.rng_len = rng_len; A.perm = perm_l.data(); A.o_v = o_v; A.o_n = o_n; A.shuffle_seed = shuffle_seed;
+        A.rng_mode = RNG_STREAM; A.vbase = 0;
         std::memset(&G, 0, sizeof(G));
         G.vbase = 0; G.n = (int32_t)n; G.t = t; G.bucket_base = 0;
         cap = nnz + 8;

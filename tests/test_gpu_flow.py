@@ -206,3 +206,59 @@ def test_flow_growth_retries(ops, flow_env):
     b = call(ops, ei, None, n, n - 1, "asc", perm)
     assert ops.last_stats["n_retries"] >= 1
     assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("o_v", ["random", "degree", "coarsen"])
+def test_frontier_mode_matches_the_oracle_in_that_mode(ops, flow_env, o_v):
+    """mode="frontier" (SURVEY section 7 step 7 / 8(b)): counter-based uniforms keyed by (seed, vertex, position) -- bit-exact
+    against the oracle run in the same mode, for every order (the round kernels draw the same numbers), different from mode="exact",
+    and mode="exact" is what a later call without the keyword gets."""
+    rng = np.random.RandomState(3)
+    for nm, ei, n in GRAPHS + [("BA6000_8", ba_graph(6000, 8, 11), 6000), ("BA1200_200", ba_graph(1200, 200, 4), 1200)]:
+        perm = rng.permutation(n)
+        for o_n in ("asc", "random"):
+            for wts in (None, sym_weights(ei, n, 5)):
+                t = n // 2
+                a = oracle.approximate_cholesky(ei, wts, n, t, o_v, o_n, perm=perm if o_v == "random" else None, shuffle_seed=9, mode="frontier")
+                b = ops.approximate_cholesky(torch.from_numpy(np.ascontiguousarray(ei)).cuda(), None if wts is None else torch.from_numpy(wts).cuda(), n, t, o_v, o_n,
+                                             perm=torch.from_numpy(perm) if o_v == "random" else None, seed=9, mode="frontier").numpy()
+                assert a.shape == b.shape and np.array_equal(a, b), (nm, o_v, o_n, wts is not None)
+    n = 3000
+    ei = ba_graph(n, 10, 2)
+    perm = rng.permutation(n)
+    ex = oracle.approximate_cholesky(ei, None, n, n // 2, o_v, "asc", perm=perm if o_v == "random" else None, shuffle_seed=9)
+    fr = oracle.approximate_cholesky(ei, None, n, n // 2, o_v, "asc", perm=perm if o_v == "random" else None, shuffle_seed=9, mode="frontier")
+    assert ex.shape != fr.shape or not np.array_equal(ex, fr)
+    b = ops.approximate_cholesky(torch.from_numpy(ei).cuda(), None, n, n // 2, o_v, "asc", perm=torch.from_numpy(perm) if o_v == "random" else None, seed=9).numpy()
+    assert ex.shape == b.shape and np.array_equal(ex, b), "the default mode is exact again"
+
+
+def test_frontier_mode_batched_and_hubs(ops, flow_env):
+    from rlap_amd import graphs
+    rng = np.random.RandomState(2)
+    sizes = [300, 777, 64, 2048]
+    eis = [graphs.barabasi_albert(s, 4, 100 + i) for i, s in enumerate(sizes)]
+    big, node_ptr = graphs.batch_disjoint(eis, sizes)
+    perm = np.concatenate([rng.permutation(s) for s in sizes]).astype(np.int64)
+    ts = [s // 2 for s in sizes]
+    for flow in ("0", "1"):   # the round kernel and the dataflow kernel draw the same numbers
+        flow_env["RLAP_FLOW"] = flow
+        sc, rp = ops.approximate_cholesky_batched(big.cuda(), None, node_ptr, ts, "random", "asc", perm=torch.from_numpy(perm), seed=5, mode="frontier")
+        sc = sc.cpu().numpy()
+        off = 0
+        for g, s in enumerate(sizes):
+            a = oracle.approximate_cholesky(eis[g].numpy(), None, s, ts[g], "random", "asc", perm=perm[off:off + s], shuffle_seed=5 + g, mode="frontier")
+            b = sc[rp[g]:rp[g + 1]].copy()
+            b[:, :2] -= off
+            assert a.shape == b.shape and np.array_equal(a, b), (flow, g)
+            off += s
+    flow_env["RLAP_FLOW"] = "1"
+    n = 3000   # hubs that take thousands of appended entries: entries one elimination pushes into a column share a tag
+    a0 = np.concatenate([np.zeros(n - 2, dtype=np.int64), np.ones(n - 2, dtype=np.int64), np.arange(2, n - 1)])
+    b0 = np.concatenate([np.arange(2, n), np.arange(2, n), np.arange(3, n)])
+    ei = symmetrize(a0, b0, n)
+    perm = np.concatenate([[0, 1], 2 + rng.permutation(n - 2)])
+    for t in (n - 3, n - 1):
+        a = oracle.approximate_cholesky(ei, None, n, t, "random", "asc", perm=perm, shuffle_seed=3, mode="frontier")
+        b = ops.approximate_cholesky(torch.from_numpy(ei).cuda(), None, n, t, "random", "asc", perm=torch.from_numpy(perm), seed=3, mode="frontier").numpy()
+        assert a.shape == b.shape and np.array_equal(a, b), t
