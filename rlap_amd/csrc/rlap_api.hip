@@ -672,6 +672,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         const char* names[11] = {"claim + wait for pend == 0", "gather", "sort by id (+ tag order)", "merge + publish", "o_n order", "cumsum + recurrence", "look-back wait", "sample", "commit (claims, chunks, stores)", "drain", "decrements"};
         std::fprintf(stderr, "[rlap flow profile] positions=%lld mean live=%.1f mean extent=%.1f; sums over all waves, us per position\n", pr[16], pr[16] ? (double)pr[17] / pr[16] : 0.0, pr[16] ? (double)pr[18] / pr[16] : 0.0);
         for (int k = 0; k < 11; ++k) std::fprintf(stderr, "  %-34s %10.3f ms total  %8.2f us/pos\n", names[k], pr[k] / 1e5, pr[16] ? pr[k] / 100.0 / (double)pr[16] : 0.0);
+        if (pr[12] || pr[15]) std::fprintf(stderr, "[rlap flow] RLAP_FLOW_MW_SORT build: %lld sorted index sets out of range; lanes affected with the prepared address %llx, with a fresh one %llx\n", pr[15], pr[13], pr[14]);
         std::fprintf(stderr, "  long columns: %lld (mean live %.0f, max %lld; %lld beyond 900, %lld beyond 1888, %lld beyond 3320 taking %.3f of %.3f ms)\n", pr[36], pr[36] ? (double)pr[37] / pr[36] : 0.0, pr[35], pr[38], pr[39], pr[32], pr[33] / 1e5, pr[34] / 1e5);
         for (int k = 1; k < 11; ++k) std::fprintf(stderr, "    %-32s %10.3f ms total  %8.2f us/col\n", names[k], pr[20 + k] / 1e5, pr[36] ? pr[20 + k] / 100.0 / (double)pr[36] : 0.0);
     } else if (ES.prof) {

@@ -153,6 +153,7 @@ template <int EC, int NW, bool MW = false>
 struct FlowBig {
     static constexpr bool SMALL = false;
     static constexpr bool MWSORT = MW;
+    long long* xdbg;   // experiment builds (RLAP_FLOW_MW_SORT): profile buffer + 12
     FlowSortLds<EC, NW>* S;  // derived from the kernel's __shared__ block (the compiler sees LDS addresses)
     FlowIdxLds<EC, NW>* X;   // the same block, index-sort view
     int32_t* stk; int32_t* tmp;
@@ -555,6 +556,19 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     }
     WAVE_SYNC();
     if (ON == ON_DESC) flow_sort<true>(B, m, lane); else flow_sort<false>(B, m, lane);
+#if RLAP_FLOW_MW_SORT
+    if constexpr (!BUF::SMALL) {
+        // experiment builds only: the same indices read twice, once with the loop index the compiler has prepared
+        // long before (the address register lives across the calls above), once with an index it cannot have prepared; a bad
+        // index stops the launch in an orderly way instead of faulting
+        bool bad = false, bad3 = false;
+        int lane2 = lane; asm volatile("" : "+v"(lane2));
+        for (int j = lane; j < m; j += 64) { const int x = B.R(j).idx; bad |= (x < 0 || x >= m); }
+        for (int j = lane2; j < m; j += 64) { const int x = B.R(j).idx; bad3 |= (x < 0 || x >= m); }
+        const uint64_t bm = __ballot(bad), bm3 = __ballot(bad3);
+        if (bm) { if (B.xdbg && lane == 0) { B.xdbg[3] += 1; B.xdbg[0] = 1; B.xdbg[1] = (long long)bm; B.xdbg[2] = (long long)bm3; } flow_fail(F, ST_INTERNAL); return false; }
+    }
+#endif
     for (int j = lane; j < m; j += 64) {
         const int x = B.R(j).idx;
         B.a_nbr[j] = B.b_nbr[x]; B.a_val[j] = B.b_val[x]; B.a_twin[j] = B.b_twin[x]; B.f_dup[j] = B.b_dup[x]; B.f_pos[j] = B.b_pos[x];
@@ -808,7 +822,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
             if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); break; }
             char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
             FlowBig<EC, NW, RLAP_FLOW_MW_SORT != 0> Gb;
-            Gb.cmd = s_cmd;
+            Gb.cmd = s_cmd; Gb.xdbg = P.prof ? P.prof + 12 : nullptr;
             const int64_t n8 = want;
             double* d = reinterpret_cast<double*>(base);
             Gb.a_val = d; Gb.b_val = d + n8; Gb.skey = d + 2 * n8; Gb.cum_ = d + 3 * n8; Gb.newv_ = d + 4 * n8;
@@ -971,7 +985,7 @@ __global__ __launch_bounds__(64 * FLOW_NW) void k_debug_flow_sort(const double* 
     for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
         const int32_t o = offs[arr], n = offs[arr + 1] - o;
         FlowBig<FLOW_EC, FLOW_NW, true> B;
-        B.S = reinterpret_cast<FlowSortLds<FLOW_EC, FLOW_NW>*>(&L); B.X = reinterpret_cast<FlowIdxLds<FLOW_EC, FLOW_NW>*>(&L); B.stk = L.stk; B.tmp = L.tmp; B.cmd = s_cmd;
+        B.S = reinterpret_cast<FlowSortLds<FLOW_EC, FLOW_NW>*>(&L); B.X = reinterpret_cast<FlowIdxLds<FLOW_EC, FLOW_NW>*>(&L); B.stk = L.stk; B.tmp = L.tmp; B.cmd = s_cmd; B.xdbg = nullptr;
         B.kind = (desc & 64) ? 0 : ((desc & 128) ? (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0) : (n <= FlowSortLds<FLOW_EC, FLOW_NW>::BIGL ? 1 : (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0)));
         B.skey = const_cast<double*>(keys) + o;
         char* base = scr + 32 * (int64_t)o + 64 * (int64_t)arr;
