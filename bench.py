@@ -41,6 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("--o_v", default=None)
     ap.add_argument("--o_n", default="asc")
     ap.add_argument("--weighted", action="store_true", help="SURVEY 8(d) variant: w ~ U(0.5,1.5) per undirected edge, seed 3 (tie-free path)")
+    ap.add_argument("--mode", choices=["exact", "frontier"], default="exact",
+                    help="c3: 'frontier' = counter-based uniforms (rlap_set_rng_mode; not the reference's stream: never the headline line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=5, help="c3: full oracle runs the CPU baseline is the median of (SURVEY 8(d) says 10; five of the headline workload take about 25 s)")
     ap.add_argument("--no-gather", action="store_true")
@@ -184,7 +186,7 @@ def main():
         perm_dev = None if perm is None else perm.to(dev)
 
         def step():
-            return ops.approximate_cholesky(ei, w_dev, n, t, o_v, o_n, perm=perm_dev, seed=7, return_device="same")
+            return ops.approximate_cholesky(ei, w_dev, n, t, o_v, o_n, perm=perm_dev, seed=7, return_device="same", mode=args.mode)
         units_per_rank_nominal = min(t, n - 1)
     else:
         Gtot, n, m = args.graphs, C5_NODES, C5_M
@@ -253,11 +255,11 @@ def main():
         shuf = torch.randperm(ei.shape[1], device=dev, generator=torch.Generator(device=dev).manual_seed(11))
         ei_u = ei[:, shuf].contiguous()
         w_u = None if w_dev is None else w_dev[shuf].contiguous()
-        ops.approximate_cholesky(ei_u, w_u, n, t, o_v, o_n, perm=perm_dev, seed=7, return_device="same")
+        ops.approximate_cholesky(ei_u, w_u, n, t, o_v, o_n, perm=perm_dev, seed=7, return_device="same", mode=args.mode)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for _ in range(2):
-            sc_u = ops.approximate_cholesky(ei_u, w_u, n, t, o_v, o_n, perm=perm_dev, seed=7, return_device="same")
+            sc_u = ops.approximate_cholesky(ei_u, w_u, n, t, o_v, o_n, perm=perm_dev, seed=7, return_device="same", mode=args.mode)
         torch.cuda.synchronize(dev)
         extra["unsorted_input_ms"] = 1e3 * (time.perf_counter() - t1) / 2
         extra["unsorted_input_setup_ms"] = ops.last_stats["ms_setup"]
@@ -298,7 +300,7 @@ def main():
         k9_bytes = 12 * L + 4 * (S + 1) + 24 * mrows              # SURVEY K9 as a whole: gather + merge + order + compaction
         peak = 8000.0
         pmc, pmc_src = _pmc_traffic()
-        default_cfg = (not c5 and n == 1_000_000 and m == 10 and o_v == "degree" and o_n == "asc" and not args.weighted)
+        default_cfg = (not c5 and n == 1_000_000 and m == 10 and o_v == "degree" and o_n == "asc" and not args.weighted and args.mode == "exact")
 
         def roof(name, b, ms):
             a = b / (ms * 1e-3) / 1e9 if (ms > 0 and b) else 0.0
@@ -309,6 +311,7 @@ def main():
         if not c5:
             workload = (f"BA(N={n}, m={m}) nnz={st['nnz']}, num_remove={n // 2}, o_v={o_v}, o_n={o_n}, "
                         + ("weights U(0.5,1.5)" if args.weighted else "unit weights") + "; one graph per GPU"
+                        + ("" if args.mode == "exact" else f"; mode={args.mode} (counter-based uniforms: NOT the reference's random stream)")
                         + ("" if world == 1 or args.no_gather else " + RCCL all-gather of sc_edge_info"))
         else:
             workload = (f"{args.graphs} x BA(N={n}, m={m}), num_remove={n // 2} each, o_v={o_v}, o_n={o_n}, unit weights; "
@@ -342,7 +345,7 @@ def main():
                 for _ in range(max(args.cpu_runs, 1)):
                     t1 = time.perf_counter()
                     ref, ost_k = oracle.approximate_cholesky(ei_cpu.numpy(), None if w_cpu is None else w_cpu.numpy(), n, n // 2, o_v, o_n,
-                                                             perm=None if perm is None else perm.numpy(), shuffle_seed=7, return_stats=True)
+                                                             perm=None if perm is None else perm.numpy(), shuffle_seed=7, return_stats=True, mode=args.mode)
                     runs.append((ost_k["t_total"], time.perf_counter() - t1, ost_k))
                 runs.sort(key=lambda r: r[0])
                 _, cpu_s, ost = runs[len(runs) // 2]
@@ -386,6 +389,8 @@ def main():
                     blk = got[int(rp[g]):int(rp[g + 1])].copy(); blk[:, :2] -= g * n
                     okc = okc and blk.shape == ref.shape and np.array_equal(blk, ref)
                 out["parity_sampled"] = bool(okc)
+        if not c5:
+            out["mode"] = args.mode
         out.update(extra)
         print(json.dumps(out))
     if world > 1:

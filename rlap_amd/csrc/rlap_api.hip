@@ -81,6 +81,7 @@ struct rlap_handle_s {
     DevBuf eqtab;   // k_eq_tables, allocated and built at rlap_create
     DevBuf small;   // two 64-bit words for rlap_approx_chol_from_edges' num_nodes reduction (max id + 1, negative-id flag)
     DevBuf prof;    // diagnostic phase profile (RLAP_PHASE_PROFILE=1), allocated at rlap_create
+    DevBuf trace;   // diagnostic per-position time stamps of the dataflow kernel (RLAP_FLOW_TRACE=<file>)
     // pinned host mirror of what a call reads back
     void* h_results = nullptr; size_t h_results_cap = 0;
     // growth factors kept across calls
@@ -573,6 +574,13 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         FP.scr = W.f_scr.as<char>(); FP.scr_entries = (int32_t)z.flow_scr;
         FP.spin_limit = 4000; FP.jitter = h->jitter; FP.poison = h->poison;
         FP.prof = ES.prof;
+        FP.trace = nullptr;
+        const char* trace_env = std::getenv("RLAP_FLOW_TRACE");   // diagnostic only: per-position time stamps, written to the named file after the call
+        if (trace_env && trace_env[0]) {
+            ENSURE(h->trace, (size_t)z.flow_Q * 48);
+            HIPCHK(hipMemsetAsync(h->trace.p, 0, (size_t)z.flow_Q * 48, s));
+            FP.trace = h->trace.as<long long>();
+        }
         if (const char* e = std::getenv("RLAP_FLOW_STALL_MS")) FP.spin_limit = std::max(1, std::atoi(e));
         HIPCHK(hipMemsetAsync(W.f_ctrl.p, 0, FC_WORDS * 4, s));
         FA.qorder = nullptr; FA.Qclaim = FA.Q;
@@ -666,6 +674,11 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     const CallResults& R = *reinterpret_cast<const CallResults*>(h->h_results);
     const int64_t* out_ptr_h = reinterpret_cast<const int64_t*>(reinterpret_cast<const CallResults*>(h->h_results) + 1);
 
+    if (flow) if (const char* trace_env = std::getenv("RLAP_FLOW_TRACE")) if (trace_env[0] && h->trace.p) {
+        std::vector<long long> tr((size_t)z.flow_Q * 6);
+        HIPCHK(hipMemcpy(tr.data(), h->trace.p, tr.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(trace_env, "wb")) { std::fwrite(tr.data(), 8, tr.size(), f); std::fclose(f); }
+    }
     if (ES.prof && flow) {
         long long pr[40];
         HIPCHK(hipMemcpy(pr, h->prof.p, sizeof(pr), hipMemcpyDeviceToHost));
@@ -796,7 +809,7 @@ int rlap_destroy(rlap_handle h) {
     if (!h) return RLAP_OK;
     DeviceGuard dg(h->device);
     if (h->h_results) (void)hipHostFree(h->h_results);
-    h->own_ws.release(); h->own_rng.release(); h->eqtab.release(); h->prof.release(); h->small.release();
+    h->own_ws.release(); h->own_rng.release(); h->eqtab.release(); h->prof.release(); h->trace.release(); h->small.release();
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : h->fork_ev) if (e) (void)hipEventDestroy(e);
     for (auto& st : h->side) if (st) (void)hipStreamDestroy(st);

@@ -139,20 +139,23 @@ struct FlowIdxLds {
     int32_t segq[2 * 3 * QCAP];
     int32_t qcnt[4];
 };
-struct IdxKeyLess { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { return key[a] < key[b]; } };
-struct IdxKeyGreater { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { return key[a] > key[b]; } };
-enum { FCMD_SORT = 1, FCMD_EXIT = 2, FCMD_RECUR = 3 };
-// The elimination kernel's long columns are sorted by the owning wave alone (MW = false): with the multi-wave sort called from
-// that kernel, LDS reads through addresses the compiler derives (ds_read) returned other data than flat loads of the same
-// generic address issued beside them, in a build-dependent number of lanes -- see DESIGN.md 8.4 (not root-caused; the sort
-// itself is exact, tests/test_gpu_flow.py drives it through k_debug_flow_sort with MW = true).  The helper wave keeps the recurrence.
+// (the keys of an index sort are in the workgroup's LDS, FlowIdxLds::key: said so, the comparisons inside wave_lvl_sort read them with ds_ instructions)
+struct IdxKeyLess { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { __builtin_assume(RLAP_IS_LDS(key)); return key[a] < key[b]; } };
+struct IdxKeyGreater { const double* key; __device__ bool operator()(uint16_t a, uint16_t b) const { __builtin_assume(RLAP_IS_LDS(key)); return key[a] > key[b]; } };
 #ifndef RLAP_FLOW_MW_SORT
-#define RLAP_FLOW_MW_SORT 0
+#define RLAP_FLOW_MW_SORT 1
 #endif
+enum { FCMD_SORT = 1, FCMD_EXIT = 2, FCMD_RECUR = 3 };
+// MW: the owner's sorts of more than FLOW_LVL_BIG keys go to all waves of the workgroup (flow_block_sort).  That function is
+// inlined into its callers on purpose: as a called function that itself calls wave_lvl_sort it left the elimination kernel reading
+// wrong LDS data afterwards (a loop-invariant address prepared at kernel entry held other values in most lanes; a freshly computed
+// address, or a flat load of the same generic address, read the right ones) -- DESIGN.md 8.4.  RLAP_FLOW_MW_SORT=0 builds the
+// kernel with single-wave sorts only.
 template <int EC, int NW, bool MW = false>
 struct FlowBig {
     static constexpr bool SMALL = false;
     static constexpr bool MWSORT = MW;
+    int gtab_words;          // words in a row from b_pos on that may hold the id set (flow_has_dup)
     long long* xdbg;   // experiment builds (RLAP_FLOW_MW_SORT): profile buffer + 12
     FlowSortLds<EC, NW>* S;  // derived from the kernel's __shared__ block (the compiler sees LDS addresses)
     FlowIdxLds<EC, NW>* X;   // the same block, index-sort view
@@ -172,8 +175,11 @@ struct FlowBig {
 };
 // The multi-wave sort of a long column whose records (kind 1) or indices + keys (kind 2) are staged in the workgroup's LDS:
 // called by ALL NW waves (the owner and its helpers) with the same arguments.
+// (inlined into its callers: called as a function that itself calls wave_lvl_sort, the elimination kernel read wrong LDS data
+// afterwards -- DESIGN.md 8.4)
+#define FLOW_BLOCK_SORT_INLINE __forceinline__
 template <int EC, int NW>
-__device__ __noinline__ bool flow_block_sort(FlowSortLds<EC, NW>* S, FlowIdxLds<EC, NW>* X, int kind, int cnt, int greater, int wave, int lane) {
+__device__ FLOW_BLOCK_SORT_INLINE bool flow_block_sort(FlowSortLds<EC, NW>* S, FlowIdxLds<EC, NW>* X, int kind, int cnt, int greater, int wave, int lane) {
     constexpr int LREG = FLOW_LVL_BIG / 64;
     if (kind == 1) {
         if (greater) return block_std_sort_lvl<SRec, SRecGreaterKey, NW, LREG>(S->rec, cnt, SRecGreaterKey(), S->ulist, S->dlist, S->segmark, S->segq, S->qcnt, FlowSortLds<EC, NW>::QCAP, S->tab, S->tab2, wave, lane);
@@ -287,10 +293,20 @@ __device__ __forceinline__ int flow_has_dup(BUF& B, int len0, int lane, int* dis
     if constexpr (BUF::SMALL) { tab = reinterpret_cast<int32_t*>(B.rec); cap = (int)(sizeof(B.rec) / 4); }
     else { tab = reinterpret_cast<int32_t*>(B.S->rec); cap = (int)(sizeof(B.S->rec) / 4); }   // (the records' part of the sort overlay)
     int bits = 31 - __builtin_clz((unsigned)cap);        // largest power of two that fits
-    if (2 * len0 > (1 << bits)) return -1;
+    if (2 * len0 > (1 << bits)) {
+        // too long for the LDS: the set goes into four of the column's scratch arrays that are idle until the merge (b_pos, f_dup, f_pos,
+        // ksel: 4 * (ext + 8) words in a row) -- a long column holds the look-back front until its count is known, and a sort costs milliseconds
+        if constexpr (BUF::SMALL) return -1;
+        else {
+            if (B.gtab_words < 2 * len0) return -1;
+            tab = B.b_pos;
+            bits = 31 - __builtin_clz((unsigned)B.gtab_words);
+        }
+    }
     while (bits > 6 && (1 << (bits - 1)) >= 2 * len0) --bits;   // no larger than needed: the table is cleared first
     const int size = 1 << bits, mask = size - 1;
     for (int q = lane; q < size; q += 64) tab[q] = -1;
+    if constexpr (!BUF::SMALL) DRAIN_STORES();   // (the table may be in global memory: the clearing stores land before the atomics)
     WAVE_SYNC();
     bool dup = false;
     int nnew = 0;
@@ -430,6 +446,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     const SlotMem M = slot_mem(A);
     long long ft_prev = P.prof ? wall_clock64() : 0;
     const long long ft_begin = ft_prev;
+#define FTRACE(k) do { if (P.trace && lane == 0) P.trace[(int64_t)idx * 6 + (k)] = wall_clock64(); } while (0)
 #define FSTAMP(k) do { if (P.prof) { const long long _t = wall_clock64(); if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + (BUF::SMALL ? 0 : 20) + (k), (unsigned long long)(_t - ft_prev)); ft_prev = _t; } } while (0)
     // ---- gather (:616-639) in physical order: appended index descending, then the CSR segment descending ----
     int len0 = 0, napp = 0;
@@ -483,13 +500,14 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     {
         bool need_tag = false, sorted = false;
         int distinct = -1;
-        const int dupk = (napp > 1 || !BUF::SMALL) ? flow_has_dup(B, len0, lane, &distinct) : 0;
-        if constexpr (!BUF::SMALL) {
-            // a long column holds the look-back front for as long as its count is unknown: the set has it before any sort
-            if (dupk >= 0 && distinct >= 0 && A.rng_mode != RNG_COUNTER) {
-                published = true;
-                if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)(distinct > 1 ? distinct - 1 : 0));
-            }
+        // every position behind this one waits for its count (look-back): the set has it before any sort, so it is asked even where
+        // the list order cannot matter (fewer than two appended entries) -- unless nobody waits (mode "frontier")
+        const bool stream = A.rng_mode != RNG_COUNTER;
+        const int dupk = (napp > 1 || !BUF::SMALL || (stream && len0 > 1)) ? flow_has_dup(B, len0, lane, &distinct) : 0;
+        if (stream && dupk >= 0 && distinct >= 0) {
+            published = true;
+            if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)(distinct > 1 ? distinct - 1 : 0));
+            FTRACE(2);
         }
         if (dupk < 0) {   // (too long for the set: sort, look, and sort again if need be)
             for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
@@ -499,7 +517,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
             bool dup = false;
             for (int p = lane + 1; p < len0; p += 64) dup |= (B.R(p).key == B.R(p - 1).key);
             need_tag = __ballot(dup) != 0ull;
-        } else need_tag = dupk > 0;
+        } else need_tag = dupk > 0 && napp > 1;   // (one appended entry or none: the gather order is the list order)
         if (need_tag) {
             // newest first: by the tag, then -- entries one elimination pushed into this column share a tag in mode "frontier" -- by the appended index
             for (int i = lane; i < napp; i += 64) B.skey[i] = -((double)B.a_tag[i] * 4194304.0 + (double)B.b_dup[i]);
@@ -543,6 +561,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     }
     const int32_t cdraw = m > 1 ? m - 1 : 0;
     if (lane == 0 && !published && A.rng_mode != RNG_COUNTER) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)cdraw);   // my count: later positions can look past me now
+    if (!published) FTRACE(2);
     WAVE_SYNC();
     FSTAMP(3);
     FLOW_JITTER(1);
@@ -650,6 +669,7 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         *last_draws = -1;
     }
     FSTAMP(6);
+    FTRACE(3);
     FLOW_JITTER(2);
 
     // ---- sample k for every position but the last (:747-756) ----
@@ -720,11 +740,14 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         if (B.f_pos[j] != FPOS_NONE) ag_add(&A.vr[B.a_nbr[j]].key, -(1 + B.f_dup[j]));
     }
     if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_PROGRESS], 1, RLX, AGT);   // progress (flow_stalled)
+    FTRACE(4);
+    if (P.trace && lane == 0) P.trace[(int64_t)idx * 6 + 5] = len0;
     FSTAMP(10);
     if (P.prof && lane == 0 && !BUF::SMALL) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 36, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 37, (unsigned long long)len0); if (len0 > 900) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 38, 1ull); if (len0 > 1888) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 39, 1ull);
         const unsigned long long dt = (unsigned long long)(wall_clock64() - ft_begin); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 34, dt); if (len0 > 3320) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 32, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 33, dt); } atomicMax(reinterpret_cast<unsigned long long*>(P.prof) + 35, (unsigned long long)len0); }
     if (P.prof && lane == 0) { atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 16, 1ull); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 17, (unsigned long long)len0); atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 18, (unsigned long long)(cp1 - cp0 + acnt)); }
 #undef FSTAMP
+#undef FTRACE
     (void)g;
     return __ballot(failed) == 0ull;
 }
@@ -732,6 +755,66 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
 // ---------------------------------------------------------------------------
 // The persistent kernel: one wave per workgroup; grid = as many as are wanted in flight (they need not all be resident: a
 // workgroup that starts late claims later positions, and what a position waits for is always held by a running wave).
+// ---------------------------------------------------------------------------
+// One claimed position whose pend counter has reached 0: short columns in the workgroup's LDS, long ones in scratch memory.
+// Returns false when the launch is being abandoned.
+template <int EC, int NW>
+__device__ __forceinline__ bool flow_position(FlowLds<EC>& L, int32_t* const s_cmd, const int ON, const Arrays& A, const FlowArrays& F, const FlowParams& P,
+                                             const int32_t idx, const int32_t v, const int lane) {
+    const int32_t g = F.qg[idx];
+    const int32_t vbase = P.gd[g].vbase;
+    const uint64_t gseed = A.shuffle_seed + (uint64_t)g;
+    const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
+    int32_t acnt = 0;
+    if (lane == 0) acnt = ag_ld(&A.vr[v].app_cnt);
+    acnt = __builtin_amdgcn_readfirstlane(acnt);
+    const int32_t ext = (cp1 - cp0) + acnt;
+    int32_t draws = 0;
+    bool ok;
+    if (ext <= EC) {
+        ok = flow_eliminate<NW>(s_cmd, ON, A, F, P, L, EC, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+    } else {
+        // long column: the arrays come from the bump allocator; the sort's records, stop lists and tables stay in LDS while they fit
+        int32_t b0 = 0;
+        const int32_t want = ext + 8;
+        if (lane == 0) b0 = ag_add(&F.ctrl[FC_SCR], want);
+        b0 = __builtin_amdgcn_readfirstlane(b0);
+        if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); return false; }
+        char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
+        FlowBig<EC, NW, RLAP_FLOW_MW_SORT != 0> Gb;
+        Gb.cmd = s_cmd; Gb.xdbg = P.prof ? P.prof + 12 : nullptr;
+        const int64_t n8 = want;
+        double* d = reinterpret_cast<double*>(base);
+        Gb.a_val = d; Gb.b_val = d + n8; Gb.skey = d + 2 * n8; Gb.cum_ = d + 3 * n8; Gb.newv_ = d + 4 * n8;
+        int32_t* ip = reinterpret_cast<int32_t*>(d + 5 * n8);
+        Gb.a_nbr = ip; Gb.a_twin = ip + n8; Gb.a_tag = ip + 2 * n8; Gb.b_nbr = ip + 3 * n8; Gb.b_twin = ip + 4 * n8; Gb.b_dup = ip + 5 * n8;
+        Gb.b_pos = ip + 6 * n8; Gb.f_dup = ip + 7 * n8; Gb.f_pos = ip + 8 * n8; Gb.ksel = ip + 9 * n8;
+        Gb.gtab_words = (int)(4 * n8);
+        char* q = reinterpret_cast<char*>(ip + 10 * n8);   // 80 * n8 bytes in front: 8-byte aligned
+        Gb.grec = reinterpret_cast<SRec*>(q);
+        Gb.gulist = reinterpret_cast<uint16_t*>(q + 16 * n8);
+        Gb.gdlist = Gb.gulist + n8;
+        Gb.gsegmark = reinterpret_cast<uint32_t*>(Gb.gdlist + n8);
+        Gb.S = reinterpret_cast<FlowSortLds<EC, NW>*>(&L);
+        Gb.X = reinterpret_cast<FlowIdxLds<EC, NW>*>(&L);
+        Gb.stk = L.stk; Gb.tmp = L.tmp;
+        Gb.kind = !FLOW_BIG_IN_LDS ? 0 : (ext <= FlowSortLds<EC, NW>::BIGL ? 1 : (ext <= FlowIdxLds<EC, NW>::IDXL ? 2 : 0));
+        const bool heavy = ext > 16384;
+        if (heavy && lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_HEAVY], 1, RLX, AGT);
+        ok = flow_eliminate<NW>(s_cmd, ON, A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
+        if (heavy && lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_HEAVY], -1, RLX, AGT);
+        if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_LONG], 1, RLX, AGT);
+    }
+    if (!ok) return false;
+    // the last position of a graph files the graph's draw count
+    if (lane == 0 && draws >= 0 && (idx + 1 >= F.Q || F.qv[idx + 1] < 0)) P.gd[g].n_draws = draws;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// The persistent kernel: one eliminating wave per workgroup (+ helper waves); grid = as many as are wanted in flight (they need
+// not all be resident: a workgroup that starts late claims later positions, and what a position waits for is always held by a
+// running wave).
 // ---------------------------------------------------------------------------
 template <int EC, int MINW, int NW>
 __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, FlowArrays F, FlowParams P) {
@@ -741,6 +824,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int ON = A.o_n;
+    constexpr bool MWS = RLAP_FLOW_MW_SORT != 0;
     if (P.poison >= 0) {
         uint32_t* const w = reinterpret_cast<uint32_t*>(&L);
         const uint32_t pat = 0x01010101u * (uint32_t)(P.poison & 0xFF);
@@ -755,7 +839,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
         if (bad) { if (threadIdx.x == 0 && blockIdx.x == 0) flow_fail(F, bad); return; }
     }
     if constexpr (NW > 1) {
-        // waves 1 .. NW-1 only help wave 0 with the sorts of its long columns: they sleep at the workgroup barrier until told
+        // waves 1 .. NW-1 only help wave 0 (the recurrence; the sorts of long columns): they sleep at the workgroup barrier until told
         if (wave > 0) {
             while (true) {
                 __syncthreads();
@@ -765,88 +849,46 @@ __global__ __launch_bounds__(64 * NW, MINW) void k_eliminate_flow(Arrays A, Flow
                         const unsigned long long cb = (unsigned long long)(uint32_t)s_cmd[4] | ((unsigned long long)(uint32_t)s_cmd[5] << 32);
                         flow_recur(reinterpret_cast<const double*>(reinterpret_cast<char*>(&L) + s_cmd[2]), reinterpret_cast<double*>(reinterpret_cast<char*>(&L) + s_cmd[3]), s_cmd[1], __longlong_as_double((long long)cb));
                     }
-                } else if constexpr (RLAP_FLOW_MW_SORT != 0)
+                } else if constexpr (MWS)
                 flow_block_sort<EC, NW>(reinterpret_cast<FlowSortLds<EC, NW>*>(&L), reinterpret_cast<FlowIdxLds<EC, NW>*>(&L), s_cmd[1], s_cmd[2], s_cmd[3], wave, lane);
                 __syncthreads();
             }
             return;
         }
     }
-    while (true) {
-        long long mt0 = P.prof ? wall_clock64() : 0;
-        int32_t idx = 0;
-        if (lane == 0) idx = ag_add(&F.ctrl[FC_CLAIM], 1);
-        idx = __builtin_amdgcn_readfirstlane(idx);
-        if (idx >= F.Qclaim) break;
-        if (F.qorder) idx = (int32_t)F.qorder[idx];   // batches: the graphs' positions interleaved (any order that keeps each graph's own is valid)
-        const int32_t v = F.qv[idx];
-        if (v < 0) continue;   // a graph's sentinel
-        if (flow_abort(F)) break;
-        // ---- wait until every earlier neighbour has committed ----
-        {
-            int spins = 0;
-            int32_t pend = 1;
-            FlowWatch fw = {-1, 0};
-            while (true) {
-                if (lane == 0) pend = ag_ld(&A.vr[v].key);
-                pend = __builtin_amdgcn_readfirstlane(pend);
-                if (pend == 0) break;
-                __builtin_amdgcn_s_sleep(2);
-                ++spins;
-                if ((spins & 63) == 0) {
-                    if (flow_abort(F)) { pend = -1; break; }
-                    if (flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); pend = -1; break; }
+    {
+        while (true) {
+            long long mt0 = (P.prof || P.trace) ? wall_clock64() : 0;
+            int32_t idx = 0;
+            if (lane == 0) idx = ag_add(&F.ctrl[FC_CLAIM], 1);
+            idx = __builtin_amdgcn_readfirstlane(idx);
+            if (idx >= F.Qclaim) break;
+            if (F.qorder) idx = (int32_t)F.qorder[idx];   // batches: the graphs' positions interleaved (any order that keeps each graph's own is valid)
+            const int32_t v = F.qv[idx];
+            if (v < 0) continue;   // a graph's sentinel
+            if (flow_abort(F)) break;
+            // ---- wait until every earlier neighbour has committed ----
+            {
+                int spins = 0;
+                int32_t pend = 1;
+                FlowWatch fw = {-1, 0};
+                while (true) {
+                    if (lane == 0) pend = ag_ld(&A.vr[v].key);
+                    pend = __builtin_amdgcn_readfirstlane(pend);
+                    if (pend == 0) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    ++spins;
+                    if ((spins & 63) == 0) {
+                        if (flow_abort(F)) { pend = -1; break; }
+                        if (flow_stalled(F, P, fw)) { flow_fail(F, ST_INTERNAL); pend = -1; break; }
+                    }
                 }
+                if (pend != 0) break;
             }
-            if (pend != 0) break;
+            if (P.prof && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 0, (unsigned long long)(wall_clock64() - mt0));
+            if (P.trace && lane == 0) { P.trace[(int64_t)idx * 6 + 0] = mt0 ? mt0 : wall_clock64(); P.trace[(int64_t)idx * 6 + 1] = wall_clock64(); }
+            if (!flow_position<EC, NW>(L, s_cmd, ON, A, F, P, idx, v, lane)) break;
         }
-        if (P.prof && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.prof) + 0, (unsigned long long)(wall_clock64() - mt0));
-        const int32_t g = F.qg[idx];
-        const int32_t vbase = P.gd[g].vbase;
-        const uint64_t gseed = A.shuffle_seed + (uint64_t)g;
-        const int32_t cp0 = A.colptr[v], cp1 = A.colptr[v + 1];
-        int32_t acnt = 0;
-        if (lane == 0) acnt = ag_ld(&A.vr[v].app_cnt);
-        acnt = __builtin_amdgcn_readfirstlane(acnt);
-        const int32_t ext = (cp1 - cp0) + acnt;
-        int32_t draws = 0;
-        bool ok;
-        if (ext <= EC) {
-            ok = flow_eliminate<NW>(s_cmd, ON, A, F, P, L, EC, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
-        } else {
-            // long column: the arrays come from the bump allocator; the sort's records, stop lists and tables stay in LDS while they fit
-            int32_t b0 = 0;
-            const int32_t want = ext + 8;
-            if (lane == 0) b0 = ag_add(&F.ctrl[FC_SCR], want);
-            b0 = __builtin_amdgcn_readfirstlane(b0);
-            if (b0 < 0 || b0 > P.scr_entries - want) { if (lane == 0) flow_fail(F, ST_FLOW_SCRATCH); break; }
-            char* base = P.scr + (int64_t)b0 * FLOW_SCR_BYTES;
-            FlowBig<EC, NW, RLAP_FLOW_MW_SORT != 0> Gb;
-            Gb.cmd = s_cmd; Gb.xdbg = P.prof ? P.prof + 12 : nullptr;
-            const int64_t n8 = want;
-            double* d = reinterpret_cast<double*>(base);
-            Gb.a_val = d; Gb.b_val = d + n8; Gb.skey = d + 2 * n8; Gb.cum_ = d + 3 * n8; Gb.newv_ = d + 4 * n8;
-            int32_t* ip = reinterpret_cast<int32_t*>(d + 5 * n8);
-            Gb.a_nbr = ip; Gb.a_twin = ip + n8; Gb.a_tag = ip + 2 * n8; Gb.b_nbr = ip + 3 * n8; Gb.b_twin = ip + 4 * n8; Gb.b_dup = ip + 5 * n8;
-            Gb.b_pos = ip + 6 * n8; Gb.f_dup = ip + 7 * n8; Gb.f_pos = ip + 8 * n8; Gb.ksel = ip + 9 * n8;
-            char* q = reinterpret_cast<char*>(ip + 10 * n8);   // 80 * n8 bytes in front: 8-byte aligned
-            Gb.grec = reinterpret_cast<SRec*>(q);
-            Gb.gulist = reinterpret_cast<uint16_t*>(q + 16 * n8);
-            Gb.gdlist = Gb.gulist + n8;
-            Gb.gsegmark = reinterpret_cast<uint32_t*>(Gb.gdlist + n8);
-            Gb.S = reinterpret_cast<FlowSortLds<EC, NW>*>(&L);
-            Gb.X = reinterpret_cast<FlowIdxLds<EC, NW>*>(&L);
-            Gb.stk = L.stk; Gb.tmp = L.tmp;
-            Gb.kind = !FLOW_BIG_IN_LDS ? 0 : (ext <= FlowSortLds<EC, NW>::BIGL ? 1 : (ext <= FlowIdxLds<EC, NW>::IDXL ? 2 : 0));
-            const bool heavy = ext > 16384;
-            if (heavy && lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_HEAVY], 1, RLX, AGT);
-            ok = flow_eliminate<NW>(s_cmd, ON, A, F, P, Gb, ext, idx, v, cp0, cp1, acnt, g, vbase, gseed, &draws);
-            if (heavy && lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_HEAVY], -1, RLX, AGT);
-            if (lane == 0) __hip_atomic_fetch_add(&F.ctrl[FC_LONG], 1, RLX, AGT);
-        }
-        if (!ok) break;
-        // the last position of a graph files the graph's draw count
-        if (lane == 0 && draws >= 0 && (idx + 1 >= F.Q || F.qv[idx + 1] < 0)) P.gd[g].n_draws = draws;
     }
     if constexpr (NW > 1) {   // every way out of the loop ends here: the helpers are sent home
         if (lane == 0) s_cmd[0] = FCMD_EXIT;
@@ -985,7 +1027,7 @@ __global__ __launch_bounds__(64 * FLOW_NW) void k_debug_flow_sort(const double* 
     for (int32_t arr = blockIdx.x; arr < narr; arr += gridDim.x) {
         const int32_t o = offs[arr], n = offs[arr + 1] - o;
         FlowBig<FLOW_EC, FLOW_NW, true> B;
-        B.S = reinterpret_cast<FlowSortLds<FLOW_EC, FLOW_NW>*>(&L); B.X = reinterpret_cast<FlowIdxLds<FLOW_EC, FLOW_NW>*>(&L); B.stk = L.stk; B.tmp = L.tmp; B.cmd = s_cmd; B.xdbg = nullptr;
+        B.S = reinterpret_cast<FlowSortLds<FLOW_EC, FLOW_NW>*>(&L); B.X = reinterpret_cast<FlowIdxLds<FLOW_EC, FLOW_NW>*>(&L); B.stk = L.stk; B.tmp = L.tmp; B.cmd = s_cmd; B.xdbg = nullptr; B.gtab_words = 0;
         B.kind = (desc & 64) ? 0 : ((desc & 128) ? (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0) : (n <= FlowSortLds<FLOW_EC, FLOW_NW>::BIGL ? 1 : (n <= FlowIdxLds<FLOW_EC, FLOW_NW>::IDXL ? 2 : 0)));
         B.skey = const_cast<double*>(keys) + o;
         char* base = scr + 32 * (int64_t)o + 64 * (int64_t)arr;

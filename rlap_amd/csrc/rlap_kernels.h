@@ -128,6 +128,8 @@ struct FlowParams {
     int32_t jitter;          // debug: waves sleep at the phase boundaries (schedule perturbation)
     int32_t poison;          // debug: LDS starts as this byte
     long long* prof;         // diagnostic (RLAP_PHASE_PROFILE=1): per-phase sums of the 100 MHz clock over all waves, nullptr in production
+    long long* trace;        // diagnostic (RLAP_FLOW_TRACE=<file>): six words per position -- 100 MHz clock at the claim, at pend == 0, at the count's publication,
+                             // after the look-back, at the end; live entries -- nullptr in production
 };
 void launch_flow_setup(hipStream_t s, const Arrays& A, const FlowArrays& F, const FlowParams& P, const int32_t* slot_col, const int32_t* nnz_p, int32_t N, int64_t Eeff,
                        uint64_t* okey, uint32_t* oval, int gbits);

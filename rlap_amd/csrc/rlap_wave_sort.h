@@ -23,6 +23,7 @@ __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
 #else
 #define ASSUME_LDS(p) ((void)0)
 #endif
+#define RLAP_IS_LDS(p) __builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)(p))
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // ---------------------------------------------------------------------------
@@ -257,6 +258,11 @@ __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int
 template <class T, class Less, int REG>
 __device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* ulist, uint16_t* dlist, uint32_t* tab, uint16_t* tab2, int lane, int depth_in = -1) {
     if (n < 2) return true;
+    // every caller's arrays are LDS, but a call passes generic pointers: flat accesses, about twice the latency of ds_ instructions and
+    // waited for one by one.  Told so, the compiler infers the address space.
+    if (!RLAP_IS_LDS(a) || !RLAP_IS_LDS(tab)) __builtin_trap();
+    __builtin_assume(RLAP_IS_LDS(a)); __builtin_assume(RLAP_IS_LDS(ulist)); __builtin_assume(RLAP_IS_LDS(dlist));
+    __builtin_assume(RLAP_IS_LDS(tab)); __builtin_assume(RLAP_IS_LDS(tab2));
     const uint64_t lt = lanemask_lt(lane);
     const uint64_t le = lt | (1ull << lane);
     const uint64_t gt = ~le;
