@@ -725,6 +725,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
         else if (R.status == ST_RNG_OVERFLOW) *retry_kind = 3;
         else if (R.status == ST_FLOW_SCRATCH) *retry_kind = 6;
         else if (R.status == ST_FLOW_REORDER) *retry_kind = 7;
+        else if (R.status == ST_INTERNAL && flow) *retry_kind = 7;   // the dataflow kernel gave up (stall watchdog, index check): once more on the round kernel
         return R.status;
     }
     if (R.flags[FLAG_SCR]) { *retry_kind = 4; *retry_need = R.scr_need; return RLAP_E_INTERNAL; }

@@ -149,7 +149,7 @@ enum { FCMD_SORT = 1, FCMD_EXIT = 2, FCMD_RECUR = 3 };
 // MW: the owner's sorts of more than FLOW_LVL_BIG keys go to all waves of the workgroup (flow_block_sort).  That function is
 // inlined into its callers on purpose: as a called function that itself calls wave_lvl_sort it left the elimination kernel reading
 // wrong LDS data afterwards (a loop-invariant address prepared at kernel entry held other values in most lanes; a freshly computed
-// address, or a flat load of the same generic address, read the right ones) -- DESIGN.md 8.4.  RLAP_FLOW_MW_SORT=0 builds the
+// address, or a flat load of the same generic address, read the right ones) -- DESIGN.md 8.6.  RLAP_FLOW_MW_SORT=0 builds the
 // kernel with single-wave sorts only.
 template <int EC, int NW, bool MW = false>
 struct FlowBig {
@@ -176,7 +176,7 @@ struct FlowBig {
 // The multi-wave sort of a long column whose records (kind 1) or indices + keys (kind 2) are staged in the workgroup's LDS:
 // called by ALL NW waves (the owner and its helpers) with the same arguments.
 // (inlined into its callers: called as a function that itself calls wave_lvl_sort, the elimination kernel read wrong LDS data
-// afterwards -- DESIGN.md 8.4)
+// afterwards -- DESIGN.md 8.6)
 #define FLOW_BLOCK_SORT_INLINE __forceinline__
 template <int EC, int NW>
 __device__ FLOW_BLOCK_SORT_INLINE bool flow_block_sort(FlowSortLds<EC, NW>* S, FlowIdxLds<EC, NW>* X, int kind, int cnt, int greater, int wave, int lane) {
@@ -575,19 +575,22 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     }
     WAVE_SYNC();
     if (ON == ON_DESC) flow_sort<true>(B, m, lane); else flow_sort<false>(B, m, lane);
-#if RLAP_FLOW_MW_SORT
     if constexpr (!BUF::SMALL) {
-        // experiment builds only: the same indices read twice, once with the loop index the compiler has prepared
-        // long before (the address register lives across the calls above), once with an index it cannot have prepared; a bad
-        // index stops the launch in an orderly way instead of faulting
-        bool bad = false, bad3 = false;
-        int lane2 = lane; asm volatile("" : "+v"(lane2));
+        // a long column's sorted indices are checked before they are used as addresses: a bad one ends the launch with ST_INTERNAL (the
+        // call then runs on the round kernel) instead of a memory fault -- the net under DESIGN.md 8.6
+        bool bad = false;
         for (int j = lane; j < m; j += 64) { const int x = B.R(j).idx; bad |= (x < 0 || x >= m); }
+        const uint64_t bm = __ballot(bad);
+#ifdef RLAP_FLOW_MW_DIAG
+        // (experiment builds: the same indices through an index register the compiler cannot have prepared before the calls above)
+        bool bad3 = false;
+        int lane2 = lane; asm volatile("" : "+v"(lane2));
         for (int j = lane2; j < m; j += 64) { const int x = B.R(j).idx; bad3 |= (x < 0 || x >= m); }
-        const uint64_t bm = __ballot(bad), bm3 = __ballot(bad3);
-        if (bm) { if (B.xdbg && lane == 0) { B.xdbg[3] += 1; B.xdbg[0] = 1; B.xdbg[1] = (long long)bm; B.xdbg[2] = (long long)bm3; } flow_fail(F, ST_INTERNAL); return false; }
-    }
+        const uint64_t bm3 = __ballot(bad3);
+        if (bm && B.xdbg && lane == 0) { B.xdbg[3] += 1; B.xdbg[0] = 1; B.xdbg[1] = (long long)bm; B.xdbg[2] = (long long)bm3; }
 #endif
+        if (bm) { flow_fail(F, ST_INTERNAL); return false; }
+    }
     for (int j = lane; j < m; j += 64) {
         const int x = B.R(j).idx;
         B.a_nbr[j] = B.b_nbr[x]; B.a_val[j] = B.b_val[x]; B.a_twin[j] = B.b_twin[x]; B.f_dup[j] = B.b_dup[x]; B.f_pos[j] = B.b_pos[x];
@@ -687,48 +690,63 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
     // ---- commit (:766-776): the new entry is appended to column k, the twin rewritten in place; live pairs are counted at the end that
     //      comes later; then my last neighbour's entry and the merged duplicates' twins die (:791-792, :655) ----
     bool failed = false;
-    for (int j0 = 0; j0 < m - 1; j0 += 64) {
-        const int j = j0 + lane;
-        const bool act = j < m - 1;
-        int32_t k = 0, a = 0, s_r = 0, pa = 0, pk = 0, ai = 0, base = FD_FAIL;
-        int c = 0;
-        double nw = 0;
-        if (act) {
-            const int32_t ks = B.ksel[j];
-            k = B.a_nbr[ks]; pk = B.f_pos[ks];
-            a = B.a_nbr[j]; pa = B.f_pos[j]; s_r = B.a_twin[j]; nw = newv[j];
+    // (a long column's arrays are in global memory: a turn of this loop is three dependent round trips -- operands, the append index,
+    // the chunk base.  Four turns go through each step together there, so that their round trips overlap)
+    constexpr int CU = BUF::SMALL ? 1 : 4;
+    for (int j0 = 0; j0 < m - 1; j0 += 64 * CU) {
+        bool act[CU];
+        int32_t k[CU], a[CU], s_r[CU], pa[CU], pk[CU], ai[CU], base[CU];
+        int c[CU];
+        double nw[CU];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int j = j0 + 64 * u + lane;
+            act[u] = j < m - 1;
+            k[u] = 0; a[u] = 0; s_r[u] = 0; pa[u] = 0; pk[u] = 0; ai[u] = 0; base[u] = FD_FAIL; c[u] = 0; nw[u] = 0;
+            if (act[u]) {
+                const int32_t ks = B.ksel[j];
+                k[u] = B.a_nbr[ks]; pk[u] = B.f_pos[ks];
+                a[u] = B.a_nbr[j]; pa[u] = B.f_pos[j]; s_r[u] = B.a_twin[j]; nw[u] = newv[j];
+            }
         }
-        {   // lanes that drew the same target form a group: ONE returning atomic per group, its indices handed out in lane (= position)
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            // lanes that drew the same target form a group: ONE returning atomic per group, its indices handed out in lane (= position)
             // order -- what one elimination pushes into a column is then in list order among itself
-            uint64_t todo = __ballot(act), mymask = 0ull;
+            uint64_t todo = __ballot(act[u]), mymask = 0ull;
             while (todo) {
                 const int ld = __builtin_ctzll(todo);
-                const int32_t kl = __shfl(k, ld);
-                const uint64_t same = __ballot(act && k == kl);
-                if (act && k == kl) mymask = same;
+                const int32_t kl = __shfl(k[u], ld);
+                const uint64_t same = __ballot(act[u] && k[u] == kl);
+                if (act[u] && k[u] == kl) mymask = same;
                 todo &= ~same;
             }
-            if (act) {
+            if (act[u]) {
                 const int leader = __builtin_ctzll(mymask);
                 int32_t base0 = 0;
-                if (lane == leader) base0 = ag_add(&A.vr[k].app_cnt, popc64(mymask));
+                if (lane == leader) base0 = ag_add(&A.vr[k[u]].app_cnt, popc64(mymask));
                 base0 = __shfl(base0, leader);
-                ai = base0 + popc64(mymask & lt);
-                c = chunk_of(ai);
+                ai[u] = base0 + popc64(mymask & lt);
+                c[u] = chunk_of(ai[u]);
             }
         }
         FLOW_JITTER(3 + (lane & 3));
-        if (act) base = flow_chunk_base(A, F, P, k, c);
-        if (act && base >= 0) {
-            const int32_t s_n = base + 1 + (ai - chunk_start(c));
-            ag_st_slot(M, s_n, nw, a, s_r);
-            ag_st(F.atag + s_n, (A.rng_mode == RNG_COUNTER) ? idx : (int32_t)(D + j));   // increasing in the sequential order either way
-            ag_st_slot(M, s_r, nw, k, s_n);
-            if (nw > 0) {
-                if (pk < pa && pa != FPOS_NONE) ag_add(&A.vr[a].key, 1);
-                if (pa < pk && pk != FPOS_NONE) ag_add(&A.vr[k].key, 1);
-            }
-        } else if (act) failed = true;
+#pragma unroll
+        for (int u = 0; u < CU; ++u) if (act[u]) base[u] = flow_chunk_base(A, F, P, k[u], c[u]);
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int j = j0 + 64 * u + lane;
+            if (act[u] && base[u] >= 0) {
+                const int32_t s_n = base[u] + 1 + (ai[u] - chunk_start(c[u]));
+                ag_st_slot(M, s_n, nw[u], a[u], s_r[u]);
+                ag_st(F.atag + s_n, (A.rng_mode == RNG_COUNTER) ? idx : (int32_t)(D + j));   // increasing in the sequential order either way
+                ag_st_slot(M, s_r[u], nw[u], k[u], s_n);
+                if (nw[u] > 0) {
+                    if (pk[u] < pa[u] && pa[u] != FPOS_NONE) ag_add(&A.vr[a[u]].key, 1);
+                    if (pa[u] < pk[u] && pk[u] != FPOS_NONE) ag_add(&A.vr[k[u]].key, 1);
+                }
+            } else if (act[u]) failed = true;
+        }
     }
     if (lane == 0 && m >= 1) ag_st_slot_val(A.e + B.a_twin[m - 1], 0.0);
     for (int i = lane; i < nk; i += 64) ag_st_slot_val(A.e + B.a_tag[i], 0.0);
@@ -944,9 +962,12 @@ __global__ void k_flow_pending(const Slot* __restrict__ ent, const int32_t* __re
 // afterwards: header links + VRec::app_chunk (the layout the output pass reads), per-graph status
 __global__ void k_flow_finish(Arrays A, FlowArrays F, GraphDesc* __restrict__ gd, int32_t N, int32_t G) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) flow_finish_vertex(A, F, i);
+    const int32_t st = F.ctrl[FC_ABORT];
+    // an abandoned launch leaves append counts ahead of their chunks (directory words EMPTY, BUSY or FAIL): no chain may be built
+    // from them, and nothing after this kernel may follow one -- the columns are cut back to their CSR part; the call is retried
+    // or fails with `st`, its rows are never handed out
+    if (i < N) { if (st == 0) flow_finish_vertex(A, F, i); else { A.vr[i].app_cnt = 0; A.vr[i].app_chunk = -1; } }
     if (i < G) {
-        const int32_t st = F.ctrl[FC_ABORT];
         if (st) gd[i].status = st;
         gd[i].pad0 = 0; gd[i].pad1 = (i == 0) ? F.ctrl[FC_LONG] : 0;   // ("rounds" has no meaning here; "singles" = long columns)
     }

@@ -208,6 +208,42 @@ def test_flow_growth_retries(ops, flow_env):
     assert a.shape == b.shape and np.array_equal(a, b)
 
 
+def test_abandoned_launch_with_appends_in_flight(ops, flow_env):
+    """A launch given up while hub columns are being appended to (pool and scratch limits of a fresh handle's size on a batch of hub
+    graphs, all vertices eliminated, waves delayed): append counts are then ahead of their chunks (directory words EMPTY / BUSY / FAIL),
+    and the kernels that follow must not build or walk chains from them.  (Soak case 41/33 of round 4: `k_flow_finish` followed such a
+    directory word into a memory fault.)  The call repeats itself and returns the oracle's rows."""
+    from rlap_amd import graphs
+    rng = np.random.RandomState(305289331 % (1 << 31))
+    n, G = 9000, 6
+    eis = []
+    for g in range(G):
+        ei = ba_graph(n, 6, 700 + g)
+        h = int(rng.randint(n))
+        others = np.flatnonzero(rng.rand(n) < 0.33)
+        others = others[others != h].astype(np.int64)
+        eis.append(symmetrize(np.concatenate([ei[0], np.full(others.size, h, dtype=np.int64)]), np.concatenate([ei[1], others]), n))
+    big, node_ptr = graphs.batch_disjoint([torch.from_numpy(e) for e in eis], [n] * G)
+    perm = np.concatenate([rng.permutation(n) for _ in range(G)]).astype(np.int64)
+    try:
+        ops.debug_set_jitter(9)
+        for limits in (dict(pool_factor=0.3), dict(pool_factor=0.6, scratch_entries=20000), dict()):
+            flow_env["RLAP_FLOW_SHAPE"] = "1"
+            if limits:
+                ops.debug_set_limits(**limits)
+            sc, rp = ops.approximate_cholesky_batched(big.cuda(), None, node_ptr, [n] * G, "random", "random", perm=torch.from_numpy(perm), seed=21)
+            sc = sc.cpu().numpy()
+            if limits:
+                assert ops.last_stats["n_retries"] >= 1, limits
+            for g in range(G):
+                a = oracle.approximate_cholesky(eis[g], None, n, n, "random", "random", perm=perm[g * n:(g + 1) * n], shuffle_seed=21 + g)
+                b = sc[rp[g]:rp[g + 1]].copy()
+                b[:, :2] -= g * n
+                assert a.shape == b.shape and np.array_equal(a, b), (limits, g)
+    finally:
+        ops.debug_set_jitter(0)
+
+
 @pytest.mark.parametrize("o_v", ["random", "degree", "coarsen"])
 def test_frontier_mode_matches_the_oracle_in_that_mode(ops, flow_env, o_v):
     """mode="frontier" (SURVEY section 7 step 7 / 8(b)): counter-based uniforms keyed by (seed, vertex, position) -- bit-exact

@@ -32,6 +32,8 @@ def main():
             os.environ.pop("RLAP_FLOW_WAVES", None)
         if waves == "1" and c["n"] * c["G"] > 30000:     # one wave = the sequential order itself: small cases only
             os.environ["RLAP_FLOW_WAVES"] = "5"
+        if os.environ.get("SOAK_VERBOSE"):
+            print("case", n_cases, soak.describe(c), "flow shape", shape, "waves", os.environ.get("RLAP_FLOW_WAVES", "auto"), flush=True)
         bad = soak.run_case(c)
         if bad:
             print("MISMATCH case", n_cases, soak.describe(c), "flow shape", shape, "waves", waves or "auto", bad, flush=True)
