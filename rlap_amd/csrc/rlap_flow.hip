@@ -276,8 +276,15 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC, NW, MW>& B, int cnt, int l
         for (int i = lane; i < cnt; i += 64) { B.grec[i].key = B.skey[i]; B.grec[i].idx = i; B.grec[i].aux = 0; }
         WAVE_SYNC();
         if (cnt <= 65000) {
-            const WaveSortPtrs WP = {B.gulist, B.gdlist, B.gsegmark, B.stk};
-            wave_std_sort<SRec, Cmp, 0>(B.grec, cnt, Cmp(), WP, lane);
+            if constexpr (LVL > 0) {
+                // partitions in global memory only while a segment is longer than the LDS record form holds; the rest is sorted through in LDS
+                FlowSortLds<EC, NW>& S = *B.S;
+                const WaveSortPtrs WL = {S.ulist, S.dlist, S.segmark, B.stk};
+                wave_std_sort_staged<SRec, Cmp, LVL / 64>(B.grec, cnt, Cmp(), B.gulist, B.gdlist, B.stk, S.rec, FlowSortLds<EC, NW>::BIGL, WL, S.tab, S.tab2, lane);
+            } else {
+                const WaveSortPtrs WP = {B.gulist, B.gdlist, B.gsegmark, B.stk};
+                wave_std_sort<SRec, Cmp, 0>(B.grec, cnt, Cmp(), WP, lane);
+            }
         } else {
             if (lane == 0) gs_std_sort<SRec>(B.grec, cnt, Cmp());   // beyond the 16-bit stop lists: one lane
         }

@@ -52,7 +52,7 @@ struct WaveSortPtrs { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32
 // REGT > 0: arrays of at most 64*REGT elements run the final phase with one lane per ELEMENT, the elements held
 // in registers between the rank computation and the stores (no second buffer).
 template <class T, class Less, int REGT = 0>
-__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane, T* obuf = nullptr) {
+__device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int lane, T* obuf = nullptr, int depth_in = -1) {
     struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
     if (n < 2) return;
     const uint64_t lt = lanemask_lt(lane);
@@ -66,6 +66,7 @@ __device__ void wave_std_sort(T* a, int n, Less less, const WaveSortPtrs W_, int
     int depth0 = 0;
     for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
     depth0 *= 2;
+    if (depth_in >= 0) depth0 = depth_in;   // a segment of a larger array: the introsort loop's remaining depth limit
     int sp = 0;
     if (lane == 0) { W.stk[0] = 0; W.stk[1] = n; W.stk[2] = depth0; }
     sp = 1;
@@ -415,7 +416,7 @@ __device__ __noinline__ bool wave_lvl_sort(T* a, int n, Less less, uint16_t* uli
 // over from the original order with wave_std_sort, which follows std::sort into its heap sort).
 // ---------------------------------------------------------------------------
 template <class T, class Less, int LREG>
-__device__ bool wave_std_sort_hyb(T* a, int n, Less less, const WaveSortPtrs W_, uint32_t* tab, uint16_t* tab2, int lane) {
+__device__ bool wave_std_sort_hyb(T* a, int n, Less less, const WaveSortPtrs W_, uint32_t* tab, uint16_t* tab2, int lane, int depth_in = -1) {
     struct { uint16_t* ulist; uint16_t* dlist; uint32_t* segmark; int32_t* stk; } W = {W_.ulist, W_.dlist, W_.segmark, W_.stk};
     if (n < 2) return true;
     const uint64_t lt = lanemask_lt(lane);
@@ -429,6 +430,7 @@ __device__ bool wave_std_sort_hyb(T* a, int n, Less less, const WaveSortPtrs W_,
     int depth0 = 0;
     for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
     depth0 *= 2;
+    if (depth_in >= 0) depth0 = depth_in;
     int sp = 0;
     if (lane == 0) { W.stk[0] = 0; W.stk[1] = n; W.stk[2] = depth0; }
     sp = 1;
@@ -545,6 +547,132 @@ __device__ bool wave_std_sort_hyb(T* a, int n, Less less, const WaveSortPtrs W_,
     }
     WAVE_SYNC();
     return true;
+}
+
+// ---------------------------------------------------------------------------
+// Arrays too long for the LDS forms: the partitions of wave_std_sort run on the array where it lies (global memory: a pass is
+// latency bound, about 1.5 us per 64 elements) only while a segment is longer than `cap` elements; a segment at or below that is
+// copied into LDS, sorted through there with the hybrid form under the loop's remaining depth limit, and copied back.  Segments
+// are disjoint and std::sort treats them independently, so the permutation is std::sort's.  No final pass: what the partitions
+// leave at 16 elements or fewer is insertion-sorted on the spot by one lane (rare at these lengths), a staged segment comes back
+// sorted.  ulist / dlist: n + 2 uint16 each beside the array (n <= 65000); stk: 3 * 48 ints, shared with the LDS sort (WL.stk is not
+// used); lrec / WL / tab / tab2: the LDS form's.
+// ---------------------------------------------------------------------------
+template <class T, class Less, int LREG>
+__device__ void wave_std_sort_staged(T* a, int n, Less less, uint16_t* ulist, uint16_t* dlist, int32_t* stk,
+                                     T* lrec, const int cap, const WaveSortPtrs WL, uint32_t* tab, uint16_t* tab2, int lane) {
+    if (n < 2) return;
+    const uint64_t lt = lanemask_lt(lane);
+    int depth0 = 0;
+    for (unsigned q = (unsigned)n; q > 1u; q >>= 1) ++depth0;
+    depth0 *= 2;
+    int sp = 0;
+    if (lane == 0) { stk[0] = 0; stk[1] = n; stk[2] = depth0; }
+    sp = 1;
+    WAVE_SYNC();
+    while (sp > 0) {
+        --sp;
+        int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+        bool done = false;
+        while (last - first > 16) {
+            const int len = last - first;
+            if (len <= cap) {
+                // (the LDS sort's own segment stack sits behind this loop's entries: together they hold no more than the depth limit, 2 log2 n <= 32 of 48)
+                const WaveSortPtrs WLi = {WL.ulist, WL.dlist, WL.segmark, stk + 3 * sp};
+                for (int i = lane; i < len; i += 64) lrec[i] = a[first + i];
+                WAVE_SYNC();
+                if (!wave_std_sort_hyb<T, Less, LREG>(lrec, len, less, WLi, tab, tab2, lane, depth)) {
+                    // a level-synchronous part met the depth limit: once more from the segment's order, following std::sort into its heap sort
+                    WAVE_SYNC();
+                    for (int i = lane; i < len; i += 64) lrec[i] = a[first + i];
+                    WAVE_SYNC();
+                    wave_std_sort<T, Less, 0>(lrec, len, less, WLi, lane, nullptr, depth);
+                }
+                WAVE_SYNC();
+                for (int i = lane; i < len; i += 64) a[first + i] = lrec[i];
+                WAVE_SYNC();
+                done = true;
+                break;
+            }
+            if (depth == 0) {
+                if (lane == 0) gs_heap_sort<T>(a, first, last, less);
+                WAVE_SYNC();
+                done = true;
+                break;
+            }
+            --depth;
+            if (lane == 0) {   // __move_median_to_first(first, first+1, mid, last-1)
+                int ia = first + 1, ib = first + len / 2, ic = last - 1;
+                int pick;
+                if (less(a[ia], a[ib])) {
+                    if (less(a[ib], a[ic])) pick = ib;
+                    else if (less(a[ia], a[ic])) pick = ic;
+                    else pick = ia;
+                } else if (less(a[ia], a[ic])) pick = ia;
+                else if (less(a[ib], a[ic])) pick = ic;
+                else pick = ib;
+                T t = a[first]; a[first] = a[pick]; a[pick] = t;
+            }
+            WAVE_SYNC();
+            const T pv = a[first];
+            int nu = 0, nd = 0;
+            for (int p0 = first + 1; p0 < last; p0 += 64) {
+                int p = p0 + lane;
+                bool stop = (p < last) && !less(a[p], pv);
+                uint64_t mk = __ballot(stop);
+                if (stop) ulist[nu + popc64(mk & lt)] = (uint16_t)p;
+                nu += popc64(mk);
+            }
+            for (int p0 = last - 1; p0 > first; p0 -= 64) {
+                int p = p0 - lane;
+                bool stop = (p > first) && !less(pv, a[p]);
+                uint64_t mk = __ballot(stop);
+                if (stop) dlist[nd + popc64(mk & lt)] = (uint16_t)p;
+                nd += popc64(mk);
+            }
+            if (lane == 0) dlist[nd] = (uint16_t)first;   // the pivot itself stops the down-scan
+            WAVE_SYNC();
+            int k = 0;
+            {
+                const int tmax = nu < nd ? nu : nd;
+                bool open = true;
+                for (int t0 = 0; t0 < tmax && open; t0 += 64) {
+                    int t = t0 + lane;
+                    bool ok = (t < tmax) && (ulist[t] < dlist[t]);
+                    uint64_t mk = __ballot(ok);
+                    uint64_t inv = ~mk;
+                    int run = inv ? __builtin_ctzll(inv) : 64;
+                    k += run;
+                    open = (run == 64);
+                }
+            }
+            T xu, xd;
+            for (int t0 = 0; t0 < k; t0 += 64) {
+                int t = t0 + lane;
+                if (t < k) { xu = a[ulist[t]]; xd = a[dlist[t]]; }
+                WAVE_SYNC();
+                if (t < k) { a[ulist[t]] = xd; a[dlist[t]] = xu; }
+                WAVE_SYNC();
+            }
+            int cut;
+            {
+                int cu = (k < nu) ? (int)ulist[k] : 0x7FFFFFFF;
+                int cd = (k > 0) ? (int)dlist[k - 1] : 0x7FFFFFFF;
+                cut = cu < cd ? cu : cd;
+            }
+            WAVE_SYNC();
+            if (last - cut > 16) {
+                if (lane == 0) { stk[3 * sp] = cut; stk[3 * sp + 1] = last; stk[3 * sp + 2] = depth; }
+                ++sp;
+            } else if (lane == 0 && last - cut > 1) {
+                gs_insertion_sort<T>(a + cut, last - cut, less);
+            }
+            WAVE_SYNC();
+            last = cut;
+        }
+        if (!done && lane == 0 && last - first > 1) gs_insertion_sort<T>(a + first, last - first, less);
+        WAVE_SYNC();
+    }
 }
 
 // ---------------------------------------------------------------------------

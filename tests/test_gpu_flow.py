@@ -46,12 +46,13 @@ def check(ops, ei, w, n, t, o_n, perm, what):
 
 
 def test_flow_long_column_sorts_match_libstdcxx(ops):
-    """The sort forms a long column goes through (records in LDS: level-synchronous up to 1024 keys, partitions on top of it beyond;
-    records in global memory) against std::sort itself: ties, runs, killers."""
+    """The sort forms a long column goes through (records in LDS: level-synchronous up to 512 keys per segment, partitions on top of it
+    beyond, on two waves; 16-bit indices in LDS; records in global memory, partitioned there and sorted through in LDS segment by
+    segment) against std::sort itself: ties, runs, killers."""
     rng = np.random.RandomState(1)
     arrays = []
     for trial in range(160):
-        n = int(rng.choice([1, 2, 16, 17, 64, 65, 200, 897, 1000, 1024, 1025, 1100, 1500, 2047, 2300, 3000, 3500, 3600, 5000, 9000]))
+        n = int(rng.choice([1, 2, 16, 17, 64, 65, 200, 897, 1000, 1024, 1025, 1100, 1500, 2047, 2300, 3000, 3097, 3500, 3600, 5000, 7000, 9000, 12000, 30000]))
         kind = trial % 6
         if kind == 0:
             k = np.ones(n)
@@ -66,7 +67,7 @@ def test_flow_long_column_sorts_match_libstdcxx(ops):
         else:
             k = np.concatenate([np.ones(n // 2), rng.rand(n - n // 2)])[rng.permutation(n)]
         arrays.append(k)
-    for n in (200, 900, 1024, 2000, 3000):
+    for n in (200, 900, 1024, 2000, 3000, 5000, 9000):
         k, hit = introsort_killer(n)
         assert hit
         arrays += [k, -k, np.concatenate([k, k[: n // 3]])]

@@ -107,6 +107,7 @@ def run_case(c, check_all=False):
     from rlap_amd import graphs, ops
     from util import sym_weights
     n, G, t, seed, o_v, o_n = c["n"], c["G"], c["t"], c["seed"], c["o_v"], c["o_n"]
+    mode = os.environ.get("SOAK_MODE", "exact")   # "frontier": counter-based uniforms in the library and in the oracle
     if c["shape"]:
         os.environ["RLAP_BATCH_SHAPE"] = c["shape"]
     else:
@@ -121,10 +122,10 @@ def run_case(c, check_all=False):
         big, node_ptr = graphs.batch_disjoint(eis, [n] * G)
         w = None if not c["weighted"] else torch.from_numpy(np.concatenate(ws))
         perm = torch.from_numpy(np.concatenate(perms)) if o_v == "random" else None
-        sc, rp = ops.approximate_cholesky_batched(big.cuda(), None if w is None else w.cuda(), node_ptr, [t] * G, o_v, o_n, perm=perm, seed=seed)
+        sc, rp = ops.approximate_cholesky_batched(big.cuda(), None if w is None else w.cuda(), node_ptr, [t] * G, o_v, o_n, perm=perm, seed=seed, mode=mode)
         sc = sc.cpu().numpy()
         for g in (range(G) if check_all else c["check"]):
-            ref = oracle.approximate_cholesky(eis[g].numpy(), ws[g], n, t, o_v, o_n, perm=perms[g], shuffle_seed=seed + g)
+            ref = oracle.approximate_cholesky(eis[g].numpy(), ws[g], n, t, o_v, o_n, perm=perms[g], shuffle_seed=seed + g, mode=mode)
             got = sc[int(rp[g]):int(rp[g + 1])].copy()
             got[:, :2] -= g * n
             if got.shape != ref.shape or not np.array_equal(got, ref):
@@ -136,15 +137,15 @@ def run_case(c, check_all=False):
         n_ref = int(e.max()) + 1                       # (isolated top ids drop out: the reference's max + 1 rule)
         frac = t / n
         got, nn = ops.approximate_cholesky_from_edges(torch.from_numpy(np.ascontiguousarray(up)).cuda(), None, None, None, o_v, o_n,
-                                                      remove_frac=frac, symmetrize=True, seed=seed)
-        ref = oracle.approximate_cholesky(e, None, n_ref, int(frac * n_ref), o_v, o_n, shuffle_seed=seed)
+                                                      remove_frac=frac, symmetrize=True, seed=seed, mode=mode)
+        ref = oracle.approximate_cholesky(e, None, n_ref, int(frac * n_ref), o_v, o_n, shuffle_seed=seed, mode=mode)
         got = got.cpu().numpy()
         if nn != n_ref or got.shape != ref.shape or not np.array_equal(got, ref):
             bad.append((0, got.shape, ref.shape))
     else:
         got = ops.approximate_cholesky(eis[0].cuda(), None if not c["weighted"] else torch.from_numpy(ws[0]).cuda(), n, t, o_v, o_n,
-                                       perm=torch.from_numpy(perms[0]) if o_v == "random" else None, seed=seed).numpy()
-        ref = oracle.approximate_cholesky(eis[0].numpy(), ws[0], n, t, o_v, o_n, perm=perms[0], shuffle_seed=seed)
+                                       perm=torch.from_numpy(perms[0]) if o_v == "random" else None, seed=seed, mode=mode).numpy()
+        ref = oracle.approximate_cholesky(eis[0].numpy(), ws[0], n, t, o_v, o_n, perm=perms[0], shuffle_seed=seed, mode=mode)
         if got.shape != ref.shape or not np.array_equal(got, ref):
             bad.append((0, got.shape, ref.shape))
     return bad
