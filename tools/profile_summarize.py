@@ -109,6 +109,15 @@ traffic = {
     "k_sc_merge_big": pick("rlap::k_sc_merge_big"),
     "k_sc_compact": pick("rlap::k_sc_compact"),
 }
+# the dataflow kernel is not launched by the default command: its traffic comes from the --o_v random passes
+try:
+    _fr = load(one("fetch_rand/**/*counter_collection.csv"), "FETCH_SIZE"); _wr = load(one("write_rand/**/*counter_collection.csv"), "WRITE_SIZE")
+    _fb = sum(sum(v for v, _ in _fr[k]) / len(_fr[k]) for k in _fr if k.startswith("rlap::k_eliminate_flow")) * 1024.0
+    _wb = sum(sum(v for v, _ in _wr[k]) / len(_wr[k]) for k in _wr if k.startswith("rlap::k_eliminate_flow")) * 1024.0
+    if _fb > 0:
+        traffic["k_eliminate_flow"] = {"fetch_bytes": _fb, "write_bytes": _wb, "command": "bench.py --o_v random --steps 1 --warmup 0 --no-cpu-baseline (separate FETCH_SIZE / WRITE_SIZE passes), per launch"}
+except SystemExit:
+    pass
 json.dump(traffic, open(os.path.join(PROF, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
 
 # 3. SQ counters of the elimination kernel
@@ -152,7 +161,7 @@ if hits_s:
         pass
     with open(os.path.join(PROF, f"{rnd}_sq_counters_k_eliminate_flow.csv"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --pmc SQ_* -- python3 bench.py --o_v random --steps 1 --warmup 0 --no-cpu-baseline; SUM over the {len(nl)} launches of k_eliminate_flow "
-                f"(grid {grid} threads in workgroups of {wg}: one wave each, two per CU on every CU); SQ_BUSY_CU_CYCLES / SQ_BUSY_CYCLES = compute units busy on average\n")
+                f"(grid {grid} threads in workgroups of {wg}: the eliminating wave and its helper, two workgroups per CU on every CU); SQ_BUSY_CU_CYCLES / SQ_BUSY_CYCLES = compute units busy on average\n")
         for k in sorted(sqr):
             f.write(f"\"{k}\",{sqr[k]:.6f}\n")
         if fr and wr:
