@@ -154,6 +154,7 @@ enum { FCMD_SORT = 1, FCMD_EXIT = 2, FCMD_RECUR = 3 };
 template <int EC, int NW, bool MW = false>
 struct FlowBig {
     static constexpr bool SMALL = false;
+    static constexpr int EC_ = EC, NW_ = NW;
     static constexpr bool MWSORT = MW;
     int gtab_words;          // words in a row from b_pos on that may hold the id set (flow_has_dup)
     long long* xdbg;   // experiment builds (RLAP_FLOW_MW_SORT): profile buffer + 12
@@ -289,6 +290,68 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC, NW, MW>& B, int cnt, int l
             if (lane == 0) gs_std_sort<SRec>(B.grec, cnt, Cmp());   // beyond the 16-bit stop lists: one lane
         }
         WAVE_SYNC();
+    }
+}
+
+// The order of keys that are known to be distinct (ids: the set said so; tags: one per uniform): radix sort instead of the std::sort
+// forms; ascending, or descending (DESC); the result is left where the ordinary sort leaves it (B.R(i)).  Returns false when the
+// column is sorted the ordinary way instead (records in global memory; too few entries to matter).
+template <bool DESC, class BUF>
+__device__ __forceinline__ bool flow_sort_distinct(BUF& B, const int32_t* ids, int len0, int lane) {
+    if (len0 <= 64) return false;   // (wave_sort64 is as fast)
+    if constexpr (BUF::SMALL) {
+        static_assert(sizeof(B.rec) >= (size_t)BUF::CAP * 12 && sizeof(B.f_pos) + sizeof(B.ksel) >= 1024 && offsetof(BUF, ksel) == offsetof(BUF, f_pos) + sizeof(B.f_pos),
+                      "radix buffers in the records' LDS, counts in f_pos | ksel (one after the other, both idle until the o_n order)");
+        uint32_t* k0 = reinterpret_cast<uint32_t*>(B.rec); uint32_t* k1 = k0 + BUF::CAP;
+        uint16_t* i0 = reinterpret_cast<uint16_t*>(k1 + BUF::CAP); uint16_t* i1 = i0 + BUF::CAP;
+        int32_t* fin = B.f_dup;
+        wave_radix_distinct(ids, len0, lane, k0, k1, i0, i1, reinterpret_cast<uint32_t*>(B.f_pos), [&](int pos, uint32_t, int src) { fin[DESC ? len0 - 1 - pos : pos] = src; });
+        WAVE_SYNC();
+        for (int i = lane; i < len0; i += 64) { const int src = fin[i]; B.rec[i].key = (double)ids[src]; B.rec[i].idx = src; }
+        WAVE_SYNC();
+        return true;
+    } else {
+        if (B.kind == 1) {
+            auto& S = *B.S;
+            const int n8 = (len0 + 7) & ~7;
+            if ((size_t)n8 * 12 > sizeof(S.rec)) return false;
+            uint32_t* k0 = reinterpret_cast<uint32_t*>(S.rec); uint32_t* k1 = k0 + n8;
+            uint16_t* i0 = reinterpret_cast<uint16_t*>(k1 + n8); uint16_t* i1 = i0 + n8;
+            uint16_t* fin = S.ulist;
+            wave_radix_distinct(ids, len0, lane, k0, k1, i0, i1, S.tab, [&](int pos, uint32_t, int src) { fin[DESC ? len0 - 1 - pos : pos] = (uint16_t)src; });
+            WAVE_SYNC();
+            for (int i = lane; i < len0; i += 64) { const int src = fin[i]; S.rec[i].key = (double)ids[src]; S.rec[i].idx = src; }
+            WAVE_SYNC();
+            return true;
+        }
+        if (B.kind == 2) {
+            auto& X = *B.X;
+            const int n8 = (len0 + 7) & ~7;
+            if ((size_t)n8 * 12 > (size_t)(reinterpret_cast<char*>(X.dlist) - reinterpret_cast<char*>(&X))) return false;
+            uint32_t* k0 = reinterpret_cast<uint32_t*>(&X); uint32_t* k1 = k0 + n8;
+            uint16_t* i0 = reinterpret_cast<uint16_t*>(k1 + n8); uint16_t* i1 = i0 + n8;
+            uint16_t* fin = X.dlist;
+            wave_radix_distinct(ids, len0, lane, k0, k1, i0, i1, X.tab, [&](int pos, uint32_t, int src) { fin[DESC ? len0 - 1 - pos : pos] = (uint16_t)src; });
+            WAVE_SYNC();
+            for (int i = lane; i < len0; i += 64) { X.key[i] = (double)ids[i]; X.idx[i] = fin[i]; }
+            WAVE_SYNC();
+            return true;
+        }
+        {   // records in global memory (beyond the LDS sort forms): the radix buffers take 12 bytes per key, so somewhat longer columns still fit the block
+            constexpr size_t AVAIL = FlowSortLds<BUF::EC_, BUF::NW_>::AVAIL;
+            const int n8 = (len0 + 7) & ~7;
+            if ((size_t)n8 * 12 + 1024 > AVAIL || len0 > 65000) return false;
+            char* base = reinterpret_cast<char*>(B.S);
+            uint32_t* k0 = reinterpret_cast<uint32_t*>(base); uint32_t* k1 = k0 + n8;
+            uint16_t* i0 = reinterpret_cast<uint16_t*>(k1 + n8); uint16_t* i1 = i0 + n8;
+            uint32_t* hist = reinterpret_cast<uint32_t*>(base + AVAIL - 1024);
+            uint16_t* fin = B.gulist;
+            wave_radix_distinct(ids, len0, lane, k0, k1, i0, i1, hist, [&](int pos, uint32_t, int src) { fin[DESC ? len0 - 1 - pos : pos] = (uint16_t)src; });
+            WAVE_SYNC();
+            for (int i = lane; i < len0; i += 64) { const int src = fin[i]; B.grec[i].key = (double)ids[src]; B.grec[i].idx = src; B.grec[i].aux = 0; }
+            WAVE_SYNC();
+            return true;
+        }
     }
 }
 
@@ -510,7 +573,8 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         // every position behind this one waits for its count (look-back): the set has it before any sort, so it is asked even where
         // the list order cannot matter (fewer than two appended entries) -- unless nobody waits (mode "frontier")
         const bool stream = A.rng_mode != RNG_COUNTER;
-        const int dupk = (napp > 1 || !BUF::SMALL || (stream && len0 > 1)) ? flow_has_dup(B, len0, lane, &distinct) : 0;
+        const bool asked = napp > 1 || !BUF::SMALL || (stream && len0 > 1);
+        const int dupk = asked ? flow_has_dup(B, len0, lane, &distinct) : 0;
         if (stream && dupk >= 0 && distinct >= 0) {
             published = true;
             if (lane == 0) ag_st64(F.lb + idx, LB_VALID | (unsigned long long)(distinct > 1 ? distinct - 1 : 0));
@@ -527,9 +591,12 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         } else need_tag = dupk > 0 && napp > 1;   // (one appended entry or none: the gather order is the list order)
         if (need_tag) {
             // newest first: by the tag, then -- entries one elimination pushed into this column share a tag in mode "frontier" -- by the appended index
-            for (int i = lane; i < napp; i += 64) B.skey[i] = -((double)B.a_tag[i] * 4194304.0 + (double)B.b_dup[i]);
-            WAVE_SYNC();
-            flow_sort<false>(B, napp, lane);   // distinct keys
+            // (stream mode: a tag is the index of one uniform, no two entries share it -- any sort gives the order; the appended entries lead the column)
+            if (!(stream && flow_sort_distinct<true>(B, B.a_tag, napp, lane))) {
+                for (int i = lane; i < napp; i += 64) B.skey[i] = -((double)B.a_tag[i] * 4194304.0 + (double)B.b_dup[i]);
+                WAVE_SYNC();
+                flow_sort<false>(B, napp, lane);   // distinct keys
+            }
             for (int i = lane; i < napp; i += 64) { const int s = B.R(i).idx; B.b_nbr[i] = B.a_nbr[s]; B.b_twin[i] = B.a_twin[s]; B.b_val[i] = B.a_val[s]; }
             WAVE_SYNC();
             for (int i = lane; i < napp; i += 64) { B.a_nbr[i] = B.b_nbr[i]; B.a_twin[i] = B.b_twin[i]; B.a_val[i] = B.b_val[i]; }
@@ -537,9 +604,13 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
             sorted = false;
         }
         if (!sorted) {
-            for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
-            WAVE_SYNC();
-            flow_sort<false>(B, len0, lane);
+            // no id repeats (the set was asked and said so): the sorted order is unique, any sort gives std::sort's permutation
+            const bool nodup = asked && dupk == 0;
+            if (!(nodup && flow_sort_distinct<false>(B, B.a_nbr, len0, lane))) {
+                for (int i = lane; i < len0; i += 64) B.skey[i] = (double)B.a_nbr[i];
+                WAVE_SYNC();
+                flow_sort<false>(B, len0, lane);
+            }
         }
     }
 

@@ -550,6 +550,64 @@ __device__ bool wave_std_sort_hyb(T* a, int n, Less less, const WaveSortPtrs W_,
 }
 
 // ---------------------------------------------------------------------------
+// DISTINCT non-negative 32-bit keys: the sorted order is unique, so std::sort's permutation is whatever sorts -- here a stable LSD
+// radix sort, 8 bits per pass, by one wave in LDS (about 100 instructions per 64 keys and pass against about 350 per key and
+// recursion level of the std::sort forms).  The caller knows that no key repeats (the dataflow kernel's id set).
+// k0, k1: n uint32 each; i0, i1: n uint16 each; hist: 256 uint32 -- all LDS.  `ids` may be anywhere.  out(position, key, source index)
+// receives the result during the last pass (it must not write into the four buffers).
+// ---------------------------------------------------------------------------
+template <class OutFn>
+__device__ __forceinline__ void wave_radix_distinct(const int32_t* ids, const int n, const int lane, uint32_t* k0, uint32_t* k1, uint16_t* i0, uint16_t* i1,
+                                                    uint32_t* hist, OutFn out) {
+    const uint64_t lt = lanemask_lt(lane);
+    int mx = 1;
+    for (int i = lane; i < n; i += 64) { const int32_t v = ids[i]; k0[i] = (uint32_t)v; i0[i] = (uint16_t)i; mx = v > mx ? v : mx; }
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+    const int passes = (32 - __builtin_clz((unsigned)mx) + 7) / 8;
+    WAVE_SYNC();
+    uint32_t* ks = k0; uint32_t* kd = k1; uint16_t* is = i0; uint16_t* id = i1;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+        const bool last = p == passes - 1;
+        for (int q = lane; q < 256; q += 64) hist[q] = 0u;
+        WAVE_SYNC();
+        for (int i = lane; i < n; i += 64) atomicAdd(&hist[(ks[i] >> shift) & 255u], 1u);
+        WAVE_SYNC();
+        {   // exclusive scan of the 256 counts: four per lane
+            const uint32_t c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            uint32_t inc = sum;
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+            const uint32_t ex = inc - sum;
+            WAVE_SYNC();
+            hist[4 * lane] = ex; hist[4 * lane + 1] = ex + c0; hist[4 * lane + 2] = ex + c0 + c1; hist[4 * lane + 3] = ex + c0 + c1 + c2;
+        }
+        WAVE_SYNC();
+        for (int b0 = 0; b0 < n; b0 += 64) {
+            const int i = b0 + lane;
+            const bool act = i < n;
+            const uint32_t key = act ? ks[i] : 0u;
+            const uint32_t dg = (key >> shift) & 255u;
+            uint64_t m = __ballot(act);   // lanes of this turn with my digit
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { const uint64_t bb = __ballot(act && ((dg >> b) & 1u)); m &= ((dg >> b) & 1u) ? bb : ~bb; }
+            const int rank = popc64(m & lt);
+            const uint32_t base = act ? hist[dg] : 0u;
+            WAVE_SYNC();
+            if (act && rank == 0) hist[dg] = base + (uint32_t)popc64(m);
+            const uint32_t pos = base + (uint32_t)rank;
+            if (act) {
+                const uint16_t src = is[i];
+                if (last) out((int)pos, key, (int)src);
+                else { kd[pos] = key; id[pos] = src; }
+            }
+            WAVE_SYNC();
+        }
+        { uint32_t* t = ks; ks = kd; kd = t; uint16_t* u = is; is = id; id = u; }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Arrays too long for the LDS forms: the partitions of wave_std_sort run on the array where it lies (global memory: a pass is
 // latency bound, about 1.5 us per 64 elements) only while a segment is longer than `cap` elements; a segment at or below that is
 // copied into LDS, sorted through there with the hybrid form under the loop's remaining depth limit, and copied back.  Segments
