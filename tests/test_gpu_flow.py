@@ -245,6 +245,27 @@ def test_abandoned_launch_with_appends_in_flight(ops, flow_env):
         ops.debug_set_jitter(0)
 
 
+def test_a_flow_launch_that_gives_up_is_repeated_on_the_round_kernel(ops, flow_env):
+    """The stall watchdog set to 1 ms on a star of 9,001 vertices (its centre's column keeps one wave busy for milliseconds while every
+    later leaf waits): the dataflow launch ends with ST_INTERNAL, the call runs once more on the round kernel, the rows are the oracle's."""
+    n = 9001
+    ei = star(n)
+    perm = np.random.RandomState(4).permutation(n)
+    perm = np.concatenate([perm[perm != 0][:3000], [0], perm[perm != 0][3000:]])   # the centre is eliminated with 6,000 leaves still there
+    a = oracle.approximate_cholesky(ei, None, n, n - 1, "random", "asc", perm=perm, shuffle_seed=3)
+    old = os.environ.get("RLAP_FLOW_STALL_MS")
+    os.environ["RLAP_FLOW_STALL_MS"] = "1"
+    try:
+        b = call(ops, ei, None, n, n - 1, "asc", perm)
+        assert ops.last_stats["n_retries"] >= 1 and ops.last_stats["n_rounds"] > 0   # (rounds: the round kernel produced the result)
+    finally:
+        if old is None:
+            os.environ.pop("RLAP_FLOW_STALL_MS", None)
+        else:
+            os.environ["RLAP_FLOW_STALL_MS"] = old
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("o_v", ["random", "degree", "coarsen"])
 def test_frontier_mode_matches_the_oracle_in_that_mode(ops, flow_env, o_v):
     """mode="frontier" (SURVEY section 7 step 7 / 8(b)): counter-based uniforms keyed by (seed, vertex, position) -- bit-exact
