@@ -243,6 +243,19 @@ def test_long_columns_random_order(ops, o_n):
             assert_same(b, a, f"{name} {o_n} {'unit' if w is None else 'weighted'}")
 
 
+@pytest.mark.parametrize("o_v", ["degree", "coarsen"])
+def test_long_serial_column_under_the_pq_orders(ops, o_v):
+    """a column beyond the wave path's LDS under the PQ orders goes through the one-lane serial elimination while the
+    helper wave waits -- it must be told that no help is needed before that starts (it used to spin through it and could run
+    into its time limit).  K_2200: every column has 2,199 entries, the first pops are serial."""
+    n = 2200
+    ei = clique(n)
+    for w in (None, sym_weights(ei, n, 4)):
+        a = oracle.approximate_cholesky(ei, w, n, 3, o_v, "asc", shuffle_seed=2)
+        b = gpu_call(ops, ei, w, n, 3, o_v, "asc", seed=2)
+        assert_same(b, a, f"K{n} {o_v} {'unit' if w is None else 'weighted'}")
+
+
 @pytest.mark.parametrize("wide", ["1", "0"])
 @pytest.mark.parametrize("o_n", ["asc", "desc", "random"])
 def test_wide_candidates_random_order(ops, monkeypatch, o_n, wide):
