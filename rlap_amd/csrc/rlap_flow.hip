@@ -789,23 +789,24 @@ __device__ __forceinline__ bool flow_eliminate(int32_t* const cmd, const int ON,
         }
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
-            // lanes that drew the same target form a group: ONE returning atomic per group, its indices handed out in lane (= position)
-            // order -- what one elimination pushes into a column is then in list order among itself
-            uint64_t todo = __ballot(act[u]), mymask = 0ull;
-            while (todo) {
-                const int ld = __builtin_ctzll(todo);
-                const int32_t kl = __shfl(k[u], ld);
-                const uint64_t same = __ballot(act[u] && k[u] == kl);
-                if (act[u] && k[u] == kl) mymask = same;
-                todo &= ~same;
-            }
-            if (act[u]) {
-                const int leader = __builtin_ctzll(mymask);
-                int32_t base0 = 0;
-                if (lane == leader) base0 = ag_add(&A.vr[k[u]].app_cnt, popc64(mymask));
-                base0 = __shfl(base0, leader);
-                ai[u] = base0 + popc64(mymask & lt);
-                c[u] = chunk_of(ai[u]);
+            if (A.rng_mode != RNG_COUNTER) {
+                // mode "exact": the tag (index of the uniform) alone orders what is pushed into a column -- every lane takes its own index
+                if (act[u]) { ai[u] = ag_add(&A.vr[k[u]].app_cnt, 1); c[u] = chunk_of(ai[u]); }
+            } else {
+                // mode "frontier": one elimination's pushes into a column share a tag and are ordered by their append index, so lanes that
+                // drew the same target form a group: ONE returning atomic per group, its indices handed out in lane (= position) order
+                // (the lanes with my target: one ballot per bit of the id instead of one pass per distinct target)
+                uint64_t mymask = __ballot(act[u]);
+#pragma unroll
+                for (int b = 0; b < 31; ++b) { const bool bit = (k[u] >> b) & 1; const uint64_t bb = __ballot(act[u] && bit); mymask &= bit ? bb : ~bb; }
+                if (act[u]) {
+                    const int leader = __builtin_ctzll(mymask);
+                    int32_t base0 = 0;
+                    if (lane == leader) base0 = ag_add(&A.vr[k[u]].app_cnt, popc64(mymask));
+                    base0 = __shfl(base0, leader);
+                    ai[u] = base0 + popc64(mymask & lt);
+                    c[u] = chunk_of(ai[u]);
+                }
             }
         }
         FLOW_JITTER(3 + (lane & 3));
