@@ -246,12 +246,13 @@ def test_abandoned_launch_with_appends_in_flight(ops, flow_env):
 
 
 def test_a_flow_launch_that_gives_up_is_repeated_on_the_round_kernel(ops, flow_env):
-    """The stall watchdog set to 1 ms on a star of 9,001 vertices (its centre's column keeps one wave busy for milliseconds while every
-    later leaf waits): the dataflow launch ends with ST_INTERNAL, the call runs once more on the round kernel, the rows are the oracle's."""
-    n = 9001
+    """The stall watchdog set to 1 ms on a star of 16,001 vertices (its centre's column of 13,000 entries keeps one wave busy for
+    milliseconds while every later leaf waits): the dataflow launch ends with ST_INTERNAL, the call runs once more on the round kernel,
+    the rows are the oracle's."""
+    n = 16001
     ei = star(n)
     perm = np.random.RandomState(4).permutation(n)
-    perm = np.concatenate([perm[perm != 0][:3000], [0], perm[perm != 0][3000:]])   # the centre is eliminated with 6,000 leaves still there
+    perm = np.concatenate([perm[perm != 0][:3000], [0], perm[perm != 0][3000:]])   # the centre is eliminated with 13,000 leaves still there
     a = oracle.approximate_cholesky(ei, None, n, n - 1, "random", "asc", perm=perm, shuffle_seed=3)
     old = os.environ.get("RLAP_FLOW_STALL_MS")
     os.environ["RLAP_FLOW_STALL_MS"] = "1"
