@@ -190,7 +190,9 @@ int rlap_rng_uniforms(rlap_handle h, int64_t count, double* d_out);
  * element that ends at position i; compared with libstdc++'s std::sort by tests/test_gpu_parity.py.
  * desc bit 0 = descending; bit 1 = arrays of at most 64 elements use the register-resident variant of the batch kernel;
  * bit 2 = the half-wave variant (arrays of at most 32 elements, two per wave; longer ones are left untouched);
- * bit 5 = the long-column sort of the dataflow elimination (rlap_flow.hip; any length up to 65000), bit 6 with it = records in global memory, bit 7 with it = 16-bit indices sorted in LDS (the form columns beyond 3,400 entries take). */
+ * bit 5 = the long-column sort of the dataflow elimination (rlap_flow.hip; any length up to 65000), bit 6 with it = records in global memory, bit 7 with it = 16-bit indices sorted in LDS (the form columns beyond 3,400 entries take);
+ * bit 8 with it = the sort's duration in 10 ns ticks instead of the first index (timing tool); bit 9 with it = the keys are distinct
+ * non-negative integers: the radix form the elimination uses where keys cannot repeat (ids of a column without multi-edges, tags). */
 int rlap_debug_wave_sort(rlap_handle h, const double* d_keys, const int32_t* d_offs, int32_t narr, int32_t desc, int32_t* d_perm_out);
 
 /* Host-side synthetic input (bench/tests): Barabasi-Albert graph as a symmetric,

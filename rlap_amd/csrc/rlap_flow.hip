@@ -1136,7 +1136,14 @@ __global__ __launch_bounds__(64 * FLOW_NW) void k_debug_flow_sort(const double* 
         B.gdlist = B.gulist + (n + 2);
         B.gsegmark = reinterpret_cast<uint32_t*>(base + 20 * (int64_t)n + 8);
         const long long t0 = wall_clock64();
-        if (desc & 1) flow_sort<true>(B, n, lane); else flow_sort<false>(B, n, lane);
+        bool done = false;
+        if (desc & 512) {   // the keys are distinct non-negative integers: the radix form the elimination uses for ids without repeats and for tags
+            int32_t* ids = reinterpret_cast<int32_t*>(base + 24 * (int64_t)n + 16);
+            for (int q = lane; q < n; q += 64) ids[q] = (int32_t)B.skey[q];
+            WAVE_SYNC();
+            done = (desc & 1) ? flow_sort_distinct<true>(B, ids, n, lane) : flow_sort_distinct<false>(B, ids, n, lane);
+        }
+        if (!done) { if (desc & 1) flow_sort<true>(B, n, lane); else flow_sort<false>(B, n, lane); }
         const long long t1 = wall_clock64();
         for (int q = lane; q < n; q += 64) perm_out[o + q] = B.R(q).idx;
         if ((desc & 256) && lane == 0 && n > 0) perm_out[o] = (int32_t)(t1 - t0);   // diagnostic: the sort's duration in 10 ns ticks instead of the first index

@@ -85,6 +85,37 @@ def test_flow_long_column_sorts_match_libstdcxx(ops):
             assert np.array_equal(got[offs[a_i]:offs[a_i + 1]], exp), (a_i, len(k), desc)
 
 
+def test_flow_radix_form_for_distinct_keys(ops):
+    """Where keys cannot repeat the elimination orders them with a radix sort (ids of a column without multi-edges, tags): the hook's
+    bit 9 runs that form in every place the records can live (short-column LDS view is exercised by the parity tests; here records in
+    LDS, 16-bit indices in LDS, records in global memory with the radix buffers in LDS, and beyond that the fall-back to the std::sort
+    form) -- distinct keys have one sorted order."""
+    rng = np.random.RandomState(5)
+    arrays = []
+    for n in (1, 2, 64, 65, 100, 512, 897, 1500, 3000, 3096, 3097, 4000, 4184, 4185, 5000, 6100, 6300, 9000, 20000):
+        for hi in (n, 1 << 20, (1 << 31) - 1):
+            if hi <= 4 * n:
+                k = rng.permutation(max(hi, n))[:n]
+            else:   # (distinct draws without materialising the population)
+                k = rng.permutation(np.unique(rng.randint(0, hi, size=3 * n + 8)))[:n]
+            assert len(k) == n and len(np.unique(k)) == n
+            arrays.append(k.astype(np.float64))
+    offs = np.zeros(len(arrays) + 1, dtype=np.int32)
+    offs[1:] = np.cumsum([len(a) for a in arrays])
+    keys = torch.from_numpy(np.concatenate(arrays)).cuda()
+    offs_t = torch.from_numpy(offs).cuda()
+    lib, h = ops._handle(torch.device("cuda", 0))
+    for desc in (32 | 512, 33 | 512, 96 | 512, 97 | 512, 160 | 512, 161 | 512):
+        out = torch.full((int(offs[-1]),), -7, dtype=torch.int32, device="cuda")
+        assert lib.rlap_debug_wave_sort(h, keys.data_ptr(), offs_t.data_ptr(), len(arrays), desc, out.data_ptr()) == 0
+        got = out.cpu().numpy()
+        for a_i, k in enumerate(arrays):
+            exp = np.argsort(k, kind="stable")
+            if desc & 1:
+                exp = exp[::-1]
+            assert np.array_equal(got[offs[a_i]:offs[a_i + 1]], exp), (a_i, len(k), desc)
+
+
 GRAPHS = [("K4", clique(4), 4), ("K6", clique(6), 6), ("P9", path(9), 9), ("star7", star(7), 7), ("K40", clique(40), 40),
           ("grid5x6", grid2d(5, 6), 30), ("BA100_50", ba_graph(100, 50, 0), 100), ("BA500_3", ba_graph(500, 3, 1), 500),
           ("BA3000_10", ba_graph(3000, 10, 2), 3000), ("BA400_40", ba_graph(400, 40, 5), 400)]
