@@ -180,15 +180,17 @@ int sort_tmp_bytes(int64_t Eeff, int64_t N, int64_t G, int64_t S, bool flow, siz
     return RLAP_OK;
 }
 
-// o_v = random runs the dataflow kernel (rlap_flow.hip) unless RLAP_FLOW=0 asks for the round kernel
-// (default: single graphs and pairs -- a batch of many small graphs is bound by the positions in flight, where one workgroup per graph
-// with a round's loads all in flight together does better: 1024 x BA(4096,8) 20 ms against 61 ms; RLAP_FLOW=1 forces it for any batch)
-inline bool flow_wanted(const rlap_handle h, int o_v, int64_t G) {
+// o_v = random runs the dataflow kernel (rlap_flow.hip) unless RLAP_FLOW=0 asks for the round kernel.  Default: single graphs and
+// pairs, and batches of up to 64 graphs of 1024 vertices or more on average -- there the waves of the whole device work on few graphs
+// (BA(4096,8), ms per call, round kernel / dataflow: 4 graphs 9.5 / 4.6, 16: 10.1 / 6.0, 32: 10.6 / 7.4, 64: 9.7-15.8 / 9.2, 96: 11.4 /
+// 11.1, 128: 11.7 / 12.4, 1024: 30 / 59).  A batch of many graphs is bound by the positions in flight, where one workgroup per graph
+// with a round's loads all in flight together does better.  RLAP_FLOW=1 forces the dataflow kernel for any batch.
+inline bool flow_wanted(const rlap_handle h, int o_v, int64_t G, int64_t n_total) {
     if (o_v != OV_RANDOM || h->flow_off_once) return false;
     const char* e = std::getenv("RLAP_FLOW");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    return G <= 2;
+    return G <= 2 || (G <= 64 && n_total >= 1024 * G);
 }
 
 constexpr int64_t SORT_SKIP_MIN = 1 << 21;   // directed entries from which the order of the input is looked at before sorting it
@@ -368,7 +370,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
     const int64_t S = surv_base[G];
     st.n_eliminated = nelim_total;
     Sizes z;
-    const bool flow = flow_wanted(h, c.o_v, G);
+    const bool flow = flow_wanted(h, c.o_v, G, N);
     { int rc = call_sizes(h, Eeff, N, G, bucket_total, S, c.o_v == OV_RANDOM && !c.d_perm, flow, nelim_total, &z); if (rc) return rc; }
     const int64_t slot_cap = z.slot_cap, log_total = z.log_total, scr_total = z.scr_total, scr_budget = z.scr_budget;
     const size_t res_bytes = z.res_bytes;
@@ -592,7 +594,7 @@ int run_once(rlap_handle h, const Call& c, int* retry_kind, int64_t* retry_need)
             if (rc) return rc;
             FA.qorder = W.sval1.as<uint32_t>(); FA.Qclaim = (int32_t)nelim_total;
         }
-        int shape = G >= 16 ? 3 : 1;   // 1: 76 KB of LDS, two workgroups per CU, four waves each (three help with long sorts); 4: the same with one wave; 3: 40 KB, four; 2: 17 KB, eight
+        int shape = G >= 48 ? 3 : 1;   // 1: 76 KB of LDS, two workgroups per CU, four waves each (three help with long sorts); 4: the same with one wave; 3: 40 KB, four; 2: 17 KB, eight
         if (const char* e = std::getenv("RLAP_FLOW_SHAPE")) { if (e[0] >= '1' && e[0] <= '4') shape = e[0] - '0'; }   // diagnostic override
         unsigned grid = (shape == 2 ? 8u : shape == 3 ? 4u : 2u) * (unsigned)h->n_cu;   // (workgroups: one position each)
         if (const char* e = std::getenv("RLAP_FLOW_WAVES")) grid = (unsigned)std::max(1, std::atoi(e));
@@ -827,7 +829,7 @@ static int ws_query(const rlap_handle h, int64_t E, int64_t n_total, int64_t G, 
     const rlap_handle hh = h ? h : &defaults;
     Sizes z;
     // bounds that hold for every split of n_total over G graphs and every num_remove: 2n+1 buckets per graph, S <= n_total
-    int rc = call_sizes(hh, Eeff, n_total, G, 2 * n_total + G, n_total, true, flow_wanted(hh, OV_RANDOM, G), n_total, &z);
+    int rc = call_sizes(hh, Eeff, n_total, G, 2 * n_total + G, n_total, true, flow_wanted(hh, OV_RANDOM, G, n_total), n_total, &z);
     if (rc) return rc;
     WS W; Carver dry{nullptr, 0};
     *ws_bytes = carve(dry, z, W);
