@@ -3487,6 +3487,15 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
     __shared__ uint32_t s_segmark[LCAP / 32 + 2];
     __shared__ int32_t s_stk[3 * 48];
     __shared__ unsigned long long s_off;
+    // HUGE: the sorts partition in global memory only down to segments of STG records, which are sorted through in LDS (wave_std_sort_staged)
+    constexpr int STG = HUGE ? 3072 : 1;
+    __shared__ Rec2 s_stg[STG];
+    __shared__ uint16_t s_stg_ul[STG + 2], s_stg_dl[STG + 2];
+    __shared__ uint32_t s_stg_mark[STG / 32 + 2];
+    __shared__ uint32_t s_stg_tab[HUGE ? 512 : 1];
+    __shared__ uint16_t s_stg_tab2[HUGE ? 512 : 2];
+    WaveSortPtrs WL;   // (assigned, not brace-initialised: a constant aggregate of LDS addresses is rejected as a static initialiser)
+    WL.ulist = s_stg_ul; WL.dlist = s_stg_dl; WL.segmark = s_stg_mark; WL.stk = s_stk;
     // stop lists of the partition emulation: in LDS behind the records (long columns), in global scratch, one region per
     // workgroup (huge columns)
     uint16_t* const mylists = HUGE ? lists + (size_t)blockIdx.x * 2 * (LCAP + 2) : reinterpret_cast<uint16_t*>(lds_R + lds_cap);
@@ -3546,7 +3555,8 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
         }
         __syncthreads();
         // sort by id (:314-315), std::sort semantics (the gather order is the traversal order)
-        wave_std_sort<Rec2>(R, len0, Rec2LessA(), WP, lane);
+        if constexpr (HUGE) wave_std_sort_staged<Rec2, Rec2LessA, 8>(R, len0, Rec2LessA(), WP.ulist, WP.dlist, s_stk, s_stg, STG, WL, s_stg_tab, s_stg_tab2, lane);
+        else wave_std_sort<Rec2>(R, len0, Rec2LessA(), WP, lane);
         __syncthreads();
         // merge (:317-329), 64 positions at a time: heads by ballot, sums in sorted order; all reads of a chunk
         // (its look-ahead included) come before its writes, which land at or below the chunk
@@ -3566,9 +3576,15 @@ __device__ __forceinline__ void sc_merge_long_body(const Arrays& A, const GraphD
             __syncthreads();
             m += popc64(mask);
         }
+        if constexpr (HUGE) {
+            if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) { const int32_t gi = vgraph[v]; Rec2LessKeyed lk; lk.vbase = gd[gi].vbase; lk.kb = keyed_order_base(A.shuffle_seed + (uint64_t)gi, v - lk.vbase, 1); wave_std_sort_staged<Rec2, Rec2LessKeyed, 8>(R, m, lk, WP.ulist, WP.dlist, s_stk, s_stg, STG, WL, s_stg_tab, s_stg_tab2, lane); }   // :339-343
+            else if (A.o_n == ON_ASC) wave_std_sort_staged<Rec2, Rec2LessB, 8>(R, m, Rec2LessB(), WP.ulist, WP.dlist, s_stk, s_stg, STG, WL, s_stg_tab, s_stg_tab2, lane);
+            else wave_std_sort_staged<Rec2, Rec2GreaterB, 8>(R, m, Rec2GreaterB(), WP.ulist, WP.dlist, s_stk, s_stg, STG, WL, s_stg_tab, s_stg_tab2, lane);   // :331-338
+        } else {
         if (A.o_n == ON_RANDOM || A.o_v == OV_COARSEN) { const int32_t gi = vgraph[v]; Rec2LessKeyed lk; lk.vbase = gd[gi].vbase; lk.kb = keyed_order_base(A.shuffle_seed + (uint64_t)gi, v - lk.vbase, 1); wave_std_sort<Rec2>(R, m, lk, WP, lane); }   // :339-343
         else if (A.o_n == ON_ASC) wave_std_sort<Rec2>(R, m, Rec2LessB(), WP, lane);
         else wave_std_sort<Rec2>(R, m, Rec2GreaterB(), WP, lane);   // :331-338
+        }
         __syncthreads();
         for (int32_t j = lane; j < m; j += 64) { tmp_nbr[toff + j] = (int32_t)R[j].a; tmp_val[toff + j] = R[j].b; }
         if (lane == 0) { cnt_out[i] = m; live_acc += (unsigned long long)len0; }
