@@ -298,7 +298,19 @@ __device__ __forceinline__ void flow_sort(FlowBig<EC, NW, MW>& B, int cnt, int l
 // column is sorted the ordinary way instead (records in global memory; too few entries to matter).
 template <bool DESC, class BUF>
 __device__ __forceinline__ bool flow_sort_distinct(BUF& B, const int32_t* ids, int len0, int lane) {
-    if (len0 <= 64) return false;   // (wave_sort64 is as fast)
+    if (len0 <= 64) {
+        // one key per lane: its position is the number of smaller keys (distinct keys: no ties to break)
+        if constexpr (!BUF::SMALL) return false;
+        else {
+            const int32_t key = lane < len0 ? ids[lane] : 0x7FFFFFFF;
+            int rank = 0;
+            for (int l = 0; l < len0; ++l) rank += (__builtin_amdgcn_readlane(key, l) < key) ? 1 : 0;
+            if (DESC) rank = len0 - 1 - rank;
+            if (lane < len0) { B.rec[rank].key = (double)key; B.rec[rank].idx = lane; }
+            WAVE_SYNC();
+            return true;
+        }
+    }
     if constexpr (BUF::SMALL) {
         static_assert(sizeof(B.rec) >= (size_t)BUF::CAP * 12 && sizeof(B.f_pos) + sizeof(B.ksel) >= 1024 && offsetof(BUF, ksel) == offsetof(BUF, f_pos) + sizeof(B.f_pos),
                       "radix buffers in the records' LDS, counts in f_pos | ksel (one after the other, both idle until the o_n order)");
